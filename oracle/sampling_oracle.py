@@ -1,0 +1,43 @@
+"""CPU restatement of the v-objective DDIM sampler (TEST ORACLE).
+
+Reference followed: diffusion/sampling.py
+  :6-9    get_alphas_sigmas      :11-14  alpha_sigma_to_t      :16-55  sample
+The literal operation order of :34-48 is kept so fp32 results are bit-comparable with the
+reference on CPU.  (torch.cuda.amp.autocast at :30 is a no-op for CPU tensors.)
+"""
+import math
+
+import torch
+
+
+def schedule(steps):
+    """sampling.py:22-24: t = linspace(1,0,steps+1)[:-1]; alpha=cos(t*pi/2); sigma=sin(t*pi/2)."""
+    t = torch.linspace(1, 0, steps + 1)[:-1]
+    return t, torch.cos(t * math.pi / 2), torch.sin(t * math.pi / 2)
+
+
+def alpha_sigma_to_t(alpha, sigma):
+    """sampling.py:11-14."""
+    return torch.atan2(sigma, alpha) / math.pi * 2
+
+
+@torch.no_grad()
+def ddim_sample(model, x, steps, eta, trace=None, **extra):
+    """sampling.py:16-55.  ``trace`` (optional list) receives each step's v."""
+    ones = x.new_ones([x.shape[0]])
+    t, alphas, sigmas = schedule(steps)
+    pred = None
+    for i in range(steps):
+        v = model(x, ones * t[i], **extra).float()
+        if trace is not None:
+            trace.append(v.clone())
+        pred = x * alphas[i] - v * sigmas[i]
+        eps = x * sigmas[i] + v * alphas[i]
+        if i < steps - 1:
+            ddim_sigma = eta * (sigmas[i + 1] ** 2 / sigmas[i] ** 2).sqrt() * \
+                (1 - alphas[i] ** 2 / alphas[i + 1] ** 2).sqrt()
+            adjusted = (sigmas[i + 1] ** 2 - ddim_sigma ** 2).sqrt()
+            x = pred * alphas[i + 1] + eps * adjusted
+            if eta:
+                x = x + torch.randn_like(x) * ddim_sigma
+    return pred

@@ -1,0 +1,122 @@
+"""CPU: pin the oracle (oracle/) against golden vectors captured from the imported reference
+(tools/make_goldens.py).  Tolerances: blocks <= 1e-6 scale-relative (same ATen kernels, different
+graph shape), DDIM tables bit-exact."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_npz, sub_sd, rel_err
+from oracle import unet_oracle as U
+from oracle import pqmf_oracle as Q
+from oracle import sampling_oracle as S
+
+
+@pytest.mark.parametrize("tag,last", [("rcb_diff", False), ("rcb_same", False), ("rcb_last", True)])
+def test_res_conv_block(golden_blocks, tag, last):
+    z = golden_blocks
+    sd = sub_sd(z, f"{tag}/sd/")
+    y = U.res_conv_block(sd, "", torch.from_numpy(z[f"{tag}/x"]), is_last=last)
+    assert rel_err(y, torch.from_numpy(z[f"{tag}/y"])) <= 1e-6
+
+
+@pytest.mark.parametrize("s", [8, 64, 256])
+def test_self_attention(golden_blocks, s):
+    z = golden_blocks
+    sd = sub_sd(z, f"attn{s}/sd/")
+    y = U.self_attention(sd, "", torch.from_numpy(z[f"attn{s}/x"]))
+    assert rel_err(y, torch.from_numpy(z[f"attn{s}/y"])) <= 1e-6
+
+
+@pytest.mark.parametrize("kern", ["linear", "cubic", "lanczos3"])
+@pytest.mark.parametrize("L", [8, 16, 4096])
+def test_resamplers(golden_blocks, kern, L):
+    z = golden_blocks
+    for d in ("down", "up"):
+        key = f"{d}_{kern}_{L}/x"
+        if key not in z.files:
+            continue
+        x = torch.from_numpy(z[key])
+        taps = torch.from_numpy(z[f"{d}_{kern}/kernel"])
+        y = U.downsample_fir(x, taps) if d == "down" else U.upsample_fir(x, taps)
+        ref = torch.from_numpy(z[f"{d}_{kern}_{L}/y"])
+        assert y.shape == ref.shape
+        assert rel_err(y, ref) <= 1e-6
+    # the stored buffers are the table (down) and 2*table (up)
+    assert np.array_equal(z[f"down_{kern}/kernel"], np.asarray(U.RESAMPLE_KERNELS[kern], np.float32))
+    assert np.array_equal(z[f"up_{kern}/kernel"], 2 * np.asarray(U.RESAMPLE_KERNELS[kern], np.float32))
+
+
+def test_fourier_and_skip(golden_blocks):
+    z = golden_blocks
+    e = U.fourier_features(torch.from_numpy(z["fourier/weight"]), torch.from_numpy(z["fourier/t"]))
+    assert torch.equal(e, torch.from_numpy(z["fourier/y"]))
+    x = torch.from_numpy(z["skip/x"])
+    assert torch.equal(torch.cat([x, x], 1), torch.from_numpy(z["skip/y"]))
+
+
+@pytest.mark.parametrize("steps", [5, 10, 100])
+def test_schedule_bit_exact(golden_blocks, steps):
+    z = golden_blocks
+    t, a, s = S.schedule(steps)
+    assert np.array_equal(t.numpy(), z[f"sched{steps}/t"])
+    assert np.array_equal(a.numpy(), z[f"sched{steps}/alpha"])
+    assert np.array_equal(s.numpy(), z[f"sched{steps}/sigma"])
+    if steps == 10:
+        assert np.array_equal(S.alpha_sigma_to_t(a, s).numpy(), z["sched10/t_back"])
+
+
+PQMF_CASES = [(1, 70, 32), (2, 70, 32), (2, 70, 4), (2, 70, 16), (2, 100, 32)]
+
+
+@pytest.mark.parametrize("ch,att,M", PQMF_CASES)
+def test_pqmf_design_and_transform(golden_pqmf, ch, att, M):
+    z = golden_pqmf
+    tag = f"pqmf_c{ch}_a{att}_m{M}"
+    d = Q.design(att, M)
+    # prototype design goes through scipy (version-dependent last digits): tight but not bitwise
+    assert d["hk"].shape == tuple(z[f"{tag}/hk"].shape)
+    assert rel_err(d["h"], torch.from_numpy(z[f"{tag}/h"])) <= 1e-6
+    assert rel_err(d["hk"], torch.from_numpy(z[f"{tag}/hk"])) <= 1e-6
+    assert rel_err(d["forward_w"], torch.from_numpy(z[f"{tag}/fw"])) <= 1e-6
+    assert rel_err(d["inverse_w"], torch.from_numpy(z[f"{tag}/iw"])) <= 1e-6
+    x = torch.from_numpy(z[f"{tag}/x"])
+    fw, iw = torch.from_numpy(z[f"{tag}/fw"]), torch.from_numpy(z[f"{tag}/iw"])
+    y = Q.analysis(x, fw, M)
+    assert y.shape == tuple(z[f"{tag}/y"].shape) == (x.shape[0], ch * M, x.shape[2] // M)
+    assert rel_err(y, torch.from_numpy(z[f"{tag}/y"])) <= 1e-6
+    # anchor that does not go through cached_conv: reference polyphase_forward + reverse_half
+    assert rel_err(y[:, :M], torch.from_numpy(z[f"{tag}/y_polyphase_ch0"])) <= 1e-5
+    r = Q.synthesis(y, iw, M)
+    assert r.shape == x.shape                                   # reference test/pqmf_test.py:9-26
+    assert rel_err(r, torch.from_numpy(z[f"{tag}/z"])) <= 1e-6
+    # near-perfect reconstruction delayed by M samples
+    err = (r[..., M:] - x[..., :-M])[..., 8 * M:-8 * M]
+    assert float(err.pow(2).mean().sqrt() / x.pow(2).mean().sqrt()) < 10 ** (-40 / 20)
+
+
+TINY = ["tiny_d3.npz", "tiny_d5.npz", "tiny_d3_pqmf4.npz", "tiny_d4_noattn_nobias.npz"]
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_tiny_models(name):
+    z = load_npz(name)
+    cfg = U.make_config(**json.loads(bytes(z["cfg"]).decode()))
+    sd = sub_sd(z, "sd/")
+    model = U.make_model_fn(sd, cfg)
+    x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["t"])
+    y = model(x, t)
+    assert rel_err(y, torch.from_numpy(z["y"])) <= 1e-6
+    trace = []
+    pred = S.ddim_sample(model, x, int(z["steps"]), 0, trace=trace)
+    assert rel_err(torch.stack(trace), torch.from_numpy(z["v_steps"])) <= 1e-5
+    assert rel_err(pred, torch.from_numpy(z["pred"])) <= 1e-5
+
+
+def test_attention_level_rule():
+    # n_attn_layers+2 levels, never level 1 (diffusion_decoder.py:85,96)
+    assert U.attn_levels(U.make_config(n_attn_layers=4)) == list(range(9, 15))
+    assert U.attn_levels(U.make_config()) == list(range(7, 15))
+    assert U.attn_levels(U.make_config(depth=3, n_attn_layers=1, c_mults=[32, 32, 64])) == [2, 3]
+    assert U.attn_levels(U.make_config(n_attn_layers=0)) == []

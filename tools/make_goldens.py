@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by IMPORTING the reference (this container only).
+
+Run:  python tools/make_goldens.py [--tier B T F] [--ref /root/reference]
+Writes small fixtures (inputs + expected outputs, never source text) to tests/golden/.
+
+The reference's hot path is Python; three of its imports are unavailable or have drifted in this
+image, so the script installs in-process stand-ins BEFORE importing (none of them is executed on
+the DiffusionAttnUnet1D path except ``cached_conv``, whose published semantics are restated):
+  * scipy.signal.kaiser (removed in SciPy 1.13; imported but unused at diffusion/pqmf.py:4)
+  * cached_conv.{Conv1d,get_padding,USE_BUFFER_CONV} (third party, not vendored; pqmf.py:10-11)
+  * local_attention / x_transformers (imported by autoencoders/transformer_ae.py:3-4, unused here)
+  * scipy.signal.firwin(nyq=...) keyword removed in SciPy 1.12 -> fs=2*nyq (pqmf.py:72)
+This file never travels as a dependency of the product; it is the committed recipe for the
+fixtures.
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def install_shims():
+    import scipy.signal
+    import scipy.signal.windows
+    if not hasattr(scipy.signal, "kaiser"):
+        scipy.signal.kaiser = scipy.signal.windows.kaiser
+
+    cc = types.ModuleType("cached_conv")
+    cc.USE_BUFFER_CONV = False
+
+    def get_padding(kernel_size, stride=1, dilation=1, mode="centered"):
+        if kernel_size == 1:
+            return (0, 0)
+        p = (kernel_size - 1) * dilation + 1
+        return (p // 2, p // 2)
+
+    class Conv1d(nn.Conv1d):
+        def __init__(self, *args, **kwargs):
+            self._pad = kwargs.get("padding", (0, 0))
+            kwargs["padding"] = 0
+            super().__init__(*args, **kwargs)
+
+        def forward(self, x):
+            return F.conv1d(F.pad(x, self._pad), self.weight, self.bias, self.stride,
+                            0, self.dilation, self.groups)
+
+    cc.get_padding = get_padding
+    cc.Conv1d = Conv1d
+    sys.modules["cached_conv"] = cc
+
+    la = types.ModuleType("local_attention")
+    lat = types.ModuleType("local_attention.transformer")
+    lat.LocalMHA = lat.FeedForward = object
+    la.transformer = lat
+    sys.modules["local_attention"] = la
+    sys.modules["local_attention.transformer"] = lat
+    xt = types.ModuleType("x_transformers")
+    xt.ContinuousTransformerWrapper = xt.Encoder = object
+    sys.modules["x_transformers"] = xt
+
+
+def import_reference(ref):
+    sys.path.insert(0, ref)
+    install_shims()
+    import scipy.signal
+    import diffusion.pqmf as P
+    P.firwin = lambda N, wc, window=None, scale=True, nyq=None: scipy.signal.firwin(
+        N, wc, window=window, scale=scale, fs=2 * nyq)
+    from decoders.diffusion_decoder import DiffusionAttnUnet1D
+    from diffusion import sampling
+    from blocks import blocks
+    return P, DiffusionAttnUnet1D, sampling, blocks
+
+
+def npz(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrays.items()})
+    print(f"  wrote {name}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def sd_arrays(sd, prefix="sd/"):
+    return {prefix + k: v for k, v in sd.items()}
+
+
+def tier_blocks(P, blocks, sampling):
+    print("tier B: per-block goldens")
+    torch.manual_seed(100)
+    out = {}
+    # ResConvBlock variants
+    for tag, (ci, cm, co, last) in dict(rcb_diff=(48, 64, 32, False), rcb_same=(32, 32, 32, False),
+                                        rcb_last=(32, 32, 2, True)).items():
+        m = blocks.ResConvBlock(ci, cm, co, is_last=last).eval()
+        with torch.no_grad():
+            for p in m.parameters():           # make the affine terms non-trivial
+                p.mul_(0.5).add_(0.05 * torch.randn_like(p))
+        x = torch.randn(2, ci, 96)
+        with torch.no_grad():
+            y = m(x)
+        out.update({f"{tag}/x": x, f"{tag}/y": y, **sd_arrays(m.state_dict(), f"{tag}/sd/")})
+    # SelfAttention1d
+    for s in (8, 64, 256):
+        m = blocks.SelfAttention1d(64, 2).eval()
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(0.05 * torch.randn_like(p))
+        x = torch.randn(2, 64, s)
+        with torch.no_grad():
+            y = m(x)
+        out.update({f"attn{s}/x": x, f"attn{s}/y": y, **sd_arrays(m.state_dict(), f"attn{s}/sd/")})
+    # resamplers
+    for kern in ("linear", "cubic", "lanczos3"):
+        for L in (8, 16, 4096):
+            x = torch.randn(2, 3, L)
+            d, u = blocks.Downsample1d(kern), blocks.Upsample1d(kern)
+            with torch.no_grad():
+                try:
+                    out[f"down_{kern}_{L}/y"] = d(x)
+                    out[f"down_{kern}_{L}/x"] = x
+                except RuntimeError as e:       # reflect pad larger than input
+                    print("   down", kern, L, "raises:", str(e)[:60])
+                try:
+                    out[f"up_{kern}_{L}/y"] = u(x)
+                    out[f"up_{kern}_{L}/x"] = x
+                except RuntimeError as e:
+                    print("   up", kern, L, "raises:", str(e)[:60])
+            out[f"down_{kern}/kernel"] = d.kernel
+            out[f"up_{kern}/kernel"] = u.kernel
+    # FourierFeatures + expand_to_planes
+    ff = blocks.FourierFeatures(1, 16)
+    t = torch.tensor([0.0, 0.25, 0.5, 1.0])
+    with torch.no_grad():
+        e = ff(t[:, None])
+    out.update({"fourier/weight": ff.weight, "fourier/t": t, "fourier/y": e,
+                "fourier/planes": blocks.expand_to_planes(e, (4, 16, 5))})
+    # SkipBlock ordering
+    sb = blocks.SkipBlock(nn.Identity())
+    x = torch.randn(1, 2, 4)
+    out.update({"skip/x": x, "skip/y": sb(x)})
+    # DDIM schedule tables (fp32 bit patterns)
+    for steps in (5, 10, 100):
+        t = torch.linspace(1, 0, steps + 1)[:-1]
+        a, s = sampling.get_alphas_sigmas(t)
+        out.update({f"sched{steps}/t": t, f"sched{steps}/alpha": a, f"sched{steps}/sigma": s})
+    tt = sampling.alpha_sigma_to_t(out["sched10/alpha"], out["sched10/sigma"])
+    out["sched10/t_back"] = tt
+    npz("blocks.npz", **out)
+
+    print("tier B: PQMF goldens (cached_conv restated -> values 'parity unpinned', see oracle)")
+    out = {}
+    for ch, att, M in ((1, 70, 32), (2, 70, 32), (2, 70, 4), (2, 70, 16), (2, 100, 32)):
+        tag = f"pqmf_c{ch}_a{att}_m{M}"
+        torch.manual_seed(7)
+        q = P.CachedPQMF(ch, att, M).eval()
+        T = M * 96
+        x = torch.randn(2, ch, T)
+        with torch.no_grad():
+            y = q(x)
+            z = q.inverse(y)
+            # cached_conv-free anchor from the reference itself (base-class polyphase path)
+            yb = P.reverse_half(P.polyphase_forward(x[:, :1], q.hk))
+        out.update({f"{tag}/h": q.h, f"{tag}/hk": q.hk, f"{tag}/fw": q.forward_conv.weight,
+                    f"{tag}/iw": q.inverse_conv.weight, f"{tag}/x": x, f"{tag}/y": y, f"{tag}/z": z,
+                    f"{tag}/y_polyphase_ch0": yb})
+    npz("pqmf.npz", **out)
+
+
+def run_model_golden(name, Model, sampling, kwargs, x_shape, seed, steps=5):
+    torch.manual_seed(seed)
+    m = Model(**kwargs).eval()
+    torch.manual_seed(seed + 1)
+    x = torch.randn(*x_shape)
+    t = torch.rand(x_shape[0])
+    with torch.no_grad():
+        y = m(x, t)
+    vs = []
+    orig = m.forward
+
+    def rec(xx, tt, **kw):
+        v = orig(xx, tt, **kw)
+        vs.append(v.clone())
+        return v
+    m.forward = rec
+    pred = sampling.sample(m, x, steps, 0)
+    m.forward = orig
+    cfg = {k: v for k, v in kwargs.items()}
+    npz(name, x=x, t=t, y=y, pred=pred, v_steps=torch.stack(vs), seed=np.int64(seed),
+        steps=np.int64(steps), cfg=np.bytes_(json.dumps(cfg).encode()), **sd_arrays(m.state_dict()))
+
+
+def tier_tiny(Model, sampling):
+    print("tier T: tiny full models")
+    run_model_golden("tiny_d3.npz", Model, sampling,
+                     dict(depth=3, c_mults=[32, 32, 64], n_attn_layers=1), (2, 2, 1024), seed=0)
+    run_model_golden("tiny_d5.npz", Model, sampling,
+                     dict(depth=5, c_mults=[32, 32, 64, 64, 96], n_attn_layers=1), (2, 2, 2048), seed=10)
+    run_model_golden("tiny_d3_pqmf4.npz", Model, sampling,
+                     dict(depth=3, c_mults=[32, 32, 64], n_attn_layers=1, pqmf_bands=4), (2, 2, 4096), seed=20)
+    run_model_golden("tiny_d4_noattn_nobias.npz", Model, sampling,
+                     dict(depth=4, c_mults=[32, 64, 64, 64], n_attn_layers=0, conv_bias=False, io_channels=1),
+                     (3, 1, 512), seed=30)
+
+
+def tier_full(Model, sampling):
+    print("tier F: full 221M-param uncond model (seeds 0/1), digests + 10-step output")
+    torch.manual_seed(0)
+    m = Model(n_attn_layers=4).eval()
+    sd = m.state_dict()
+    h = hashlib.sha256()
+    per = {}
+    for k, v in sd.items():
+        b = v.detach().contiguous().numpy().tobytes()
+        h.update(k.encode())
+        h.update(b)
+        flat = v.detach().reshape(-1)
+        per[k] = dict(shape=list(v.shape), sum=float(flat.double().sum()),
+                      head=[float(z) for z in flat[:4]])
+    n_params = sum(p.numel() for p in m.parameters())
+    torch.manual_seed(1)
+    x = torch.randn(1, 2, 65536)
+    vs = []
+    orig = m.forward
+
+    def rec(xx, tt, **kw):
+        v = orig(xx, tt, **kw)
+        if len(vs) < 1:
+            vs.append(v.clone())
+        return v
+    m.forward = rec
+    import time
+    t0 = time.time()
+    pred = sampling.sample(m, x, 10, 0)
+    dt = time.time() - t0
+    meta = dict(n_params=n_params, n_tensors=len(sd), sd_sha256=h.hexdigest(),
+                pred_sha256=hashlib.sha256(pred.numpy().tobytes()).hexdigest(),
+                pred_mean=float(pred.mean()), pred_std=float(pred.std()), pred_absmax=float(pred.abs().max()),
+                wall_s=dt, threads=torch.get_num_threads(), torch=torch.__version__)
+    print("  ", meta)
+    with open(os.path.join(OUT, "full_digest.json"), "w") as f:
+        json.dump(dict(meta=meta, tensors=per), f)
+    npz("full_seed0_steps10.npz", pred=pred, v0=vs[0])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--tier", nargs="+", default=["B", "T", "F"])
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    P, Model, sampling, blocks = import_reference(a.ref)
+    if "B" in a.tier:
+        tier_blocks(P, blocks, sampling)
+    if "T" in a.tier:
+        tier_tiny(Model, sampling)
+    if "F" in a.tier:
+        tier_full(Model, sampling)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,301 @@
+// extern "C" surface of libadk.so (declared in include/adk.h): host-side validation + dispatch.
+// Every argument check happens BEFORE a launch: a kernel never sees a shape its grid does not match.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "adk_common.h"
+
+int launch_conv(const adk_op& op, hipStream_t st);
+int conv_cotile(int Cout);
+int conv_partials_count(int Cout, int CoutPad, int L);
+int launch_gn(const adk_op& op, hipStream_t st, bool apply);
+int gn_partials_count(int dtype, int C, int L);
+int launch_fir(const adk_op& op, hipStream_t st, bool up);
+int launch_attn(const adk_op& op, hipStream_t st);
+int launch_pqmf(const adk_op& op, hipStream_t st, bool synth);
+int launch_pack_input(const adk_op& op, hipStream_t st);
+int launch_unpack_output(const adk_op& op, hipStream_t st);
+int launch_ddim_update(const adk_op& op, hipStream_t st);
+int launch_step_advance(const adk_op& op, hipStream_t st);
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define REQUIRE(cond, ...) do { if (!(cond)) return fail(ADK_EINVAL, __VA_ARGS__); } while (0)
+
+static inline int cb_of(int dtype) { return dtype == ADK_F32 ? 16 : 32; }
+
+static int check_geo(const adk_op& o, const char* what)
+{
+    REQUIRE(o.dtype == ADK_F32 || o.dtype == ADK_BF16, "%s: dtype %d unsupported", what, o.dtype);
+    REQUIRE(o.B >= 1 && o.L >= 1 && o.P >= 0, "%s: bad geometry B=%d L=%d P=%d", what, o.B, o.L, o.P);
+    REQUIRE((long long)o.B * (o.L + 2 * o.P) < (1LL << 25), "%s: B*(L+2P)=%lld rows exceed the 2^25 per-plane limit",
+            what, (long long)o.B * (o.L + 2 * o.P));
+    return ADK_OK;
+}
+
+static int validate(const adk_op& o)
+{
+    int rc;
+    switch (o.kind) {
+    case ADK_OP_CONV: {
+        if ((rc = check_geo(o, "conv1d"))) return rc;
+        const int cb = cb_of(o.dtype);
+        REQUIRE(o.taps == 1 || o.taps == 5, "conv1d: taps=%d unsupported (1 or 5)", o.taps);
+        REQUIRE(o.P >= o.taps / 2, "conv1d: halo P=%d < taps/2=%d", o.P, o.taps / 2);
+        REQUIRE(o.Cin >= cb && o.Cin % cb == 0, "conv1d: Cin=%d not a multiple of %d", o.Cin, cb);
+        REQUIRE(o.Cout >= 1, "conv1d: Cout=%d", o.Cout);
+        const int bn = conv_cotile(o.Cout);
+        REQUIRE(o.CoutPad >= o.Cout && o.CoutPad % bn == 0, "conv1d: CoutPad=%d must be a multiple of %d >= Cout=%d",
+                o.CoutPad, bn, o.Cout);
+        REQUIRE(o.x && o.w && o.y, "conv1d: null tensor");
+        return ADK_OK;
+    }
+    case ADK_OP_GN_APPLY:
+        if ((rc = check_geo(o, "gn_apply"))) return rc;
+        REQUIRE(o.Cin >= 1 && o.x && o.y && o.gamma && o.beta, "gn_apply: null tensor / C=%d", o.Cin);
+        REQUIRE(o.partials_in && o.n_partials_in >= 1, "gn_apply: needs input partials");
+        REQUIRE(o.f0 > 0.f, "gn_apply: eps=%g", (double)o.f0);
+        return ADK_OK;
+    case ADK_OP_GN_STATS:
+        if ((rc = check_geo(o, "gn_stats"))) return rc;
+        REQUIRE(o.Cin >= 1 && o.x && o.partials_out, "gn_stats: null tensor");
+        return ADK_OK;
+    case ADK_OP_FIR_DOWN:
+    case ADK_OP_FIR_UP: {
+        const bool up = o.kind == ADK_OP_FIR_UP;
+        if ((rc = check_geo(o, up ? "fir_up2" : "fir_down2"))) return rc;
+        REQUIRE(o.taps == 4 || o.taps == 8 || o.taps == 12, "fir: K=%d unsupported (4, 8, 12)", o.taps);
+        REQUIRE(o.x && o.y && o.w && o.Cin >= 1, "fir: null tensor");
+        if (up) REQUIRE(o.taps / 4 < o.L, "fir_up2: reflect padding %d must be smaller than the input length %d "
+                        "(the reference raises the same way)", o.taps / 4, o.L);
+        else {
+            REQUIRE(o.L % 2 == 0, "fir_down2: L=%d must be even", o.L);
+            REQUIRE(o.taps / 2 - 1 < o.L, "fir_down2: reflect padding %d must be smaller than the input length %d "
+                    "(the reference raises the same way)", o.taps / 2 - 1, o.L);
+        }
+        return ADK_OK;
+    }
+    case ADK_OP_ATTN:
+        if ((rc = check_geo(o, "attn1d"))) return rc;
+        REQUIRE(o.Cin >= 32 && o.Cin % 32 == 0, "attn1d: C=%d must be a multiple of the head dim 32", o.Cin);
+        REQUIRE(o.x && o.y, "attn1d: null tensor");
+        return ADK_OK;
+    case ADK_OP_PACK_INPUT:
+        if ((rc = check_geo(o, "pack_input"))) return rc;
+        REQUIRE(o.Cin >= 1 && o.x && o.w && o.y && o.aux0, "pack_input: null tensor");
+        return ADK_OK;
+    case ADK_OP_UNPACK_OUTPUT:
+        if ((rc = check_geo(o, "unpack_output"))) return rc;
+        REQUIRE(o.Cin >= 1 && o.x && o.y, "unpack_output: null tensor");
+        return ADK_OK;
+    case ADK_OP_PQMF_ANALYSIS:
+    case ADK_OP_PQMF_SYNTHESIS: {
+        const int M = o.i0;
+        REQUIRE(M >= 2 && M <= 64 && (M & (M - 1)) == 0, "pqmf: M=%d must be a power of two in [2,64]", M);
+        REQUIRE(o.B >= 1 && o.Cin >= 1 && o.L >= 1 && o.x && o.w && o.y, "pqmf: bad arguments");
+        REQUIRE(o.taps >= 1 && (o.taps & 1), "pqmf: filter length %d must be odd", o.taps);
+        if (o.kind == ADK_OP_PQMF_ANALYSIS) {
+            REQUIRE(o.L % M == 0, "pqmf_analysis: T=%d not a multiple of M=%d", o.L, M);
+            REQUIRE(o.taps <= 2049, "pqmf_analysis: K=%d too long", o.taps);
+        } else REQUIRE(o.taps <= 129, "pqmf_synthesis: Kt=%d too long", o.taps);
+        return ADK_OK;
+    }
+    case ADK_OP_DDIM_UPDATE:
+        REQUIRE(o.x && o.y && o.aux0 && o.aux1, "ddim_update: null tensor");
+        REQUIRE(!(o.flags & ADK_FLAG_NOISE) || o.residual, "ddim_update: noise flag without a noise tensor");
+        REQUIRE(o.i0 >= 0 && o.i1 >= 0 && (o.i0 > 0 || o.i1 > 0), "ddim_update: n=0");
+        return ADK_OK;
+    case ADK_OP_STEP_ADVANCE:
+        REQUIRE(o.y, "step_advance: null counter");
+        return ADK_OK;
+    default:
+        return fail(ADK_EINVAL, "unknown op kind %d", o.kind);
+    }
+}
+
+static int dispatch(const adk_op& o, hipStream_t st)
+{
+    switch (o.kind) {
+    case ADK_OP_CONV: return launch_conv(o, st);
+    case ADK_OP_GN_APPLY: return launch_gn(o, st, true);
+    case ADK_OP_GN_STATS: return launch_gn(o, st, false);
+    case ADK_OP_FIR_DOWN: return launch_fir(o, st, false);
+    case ADK_OP_FIR_UP: return launch_fir(o, st, true);
+    case ADK_OP_ATTN: return launch_attn(o, st);
+    case ADK_OP_PACK_INPUT: return launch_pack_input(o, st);
+    case ADK_OP_UNPACK_OUTPUT: return launch_unpack_output(o, st);
+    case ADK_OP_PQMF_ANALYSIS: return launch_pqmf(o, st, false);
+    case ADK_OP_PQMF_SYNTHESIS: return launch_pqmf(o, st, true);
+    case ADK_OP_DDIM_UPDATE: return launch_ddim_update(o, st);
+    case ADK_OP_STEP_ADVANCE: return launch_step_advance(o, st);
+    }
+    return ADK_EINVAL;
+}
+
+extern "C" {
+
+int adk_version(void) { return 100; }
+
+const char* adk_last_error(void) { return g_err; }
+
+int adk_run_plan(const adk_op* ops, int n, void* stream)
+{
+    if (!ops || n < 0) return fail(ADK_EINVAL, "adk_run_plan: null plan");
+    for (int i = 0; i < n; ++i) {            // validate everything first: all-or-nothing
+        const int rc = validate(ops[i]);
+        if (rc) {
+            char tmp[400];
+            snprintf(tmp, sizeof tmp, "%s", g_err);
+            return fail(rc, "op %d: %s", i, tmp);
+        }
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    for (int i = 0; i < n; ++i) {
+        const int rc = dispatch(ops[i], st);
+        if (rc) return fail(rc, "op %d (kind %d): launch failed: %s", i, ops[i].kind, hipGetErrorString(hipGetLastError()));
+    }
+    return ADK_OK;
+}
+
+int adk_validate_plan(const adk_op* ops, int n)
+{
+    if (!ops || n < 0) return fail(ADK_EINVAL, "adk_validate_plan: null plan");
+    for (int i = 0; i < n; ++i) {
+        const int rc = validate(ops[i]);
+        if (rc) {
+            char tmp[400];
+            snprintf(tmp, sizeof tmp, "%s", g_err);
+            return fail(rc, "op %d: %s", i, tmp);
+        }
+    }
+    return ADK_OK;
+}
+
+int adk_partials_count(const adk_op* op)
+{
+    if (!op) return 0;
+    if (op->kind == ADK_OP_CONV) return conv_partials_count(op->Cout, op->CoutPad, op->L);
+    if (op->kind == ADK_OP_GN_APPLY || op->kind == ADK_OP_GN_STATS) return gn_partials_count(op->dtype, op->Cin, op->L);
+    return 0;
+}
+
+int adk_conv_cotile(int dtype, int Cout, int L) { (void)dtype; (void)L; return conv_cotile(Cout); }
+
+static adk_op zero_op(int kind, int dtype)
+{
+    adk_op o;
+    memset(&o, 0, sizeof o);
+    o.kind = kind; o.dtype = dtype;
+    return o;
+}
+
+int adk_conv1d(int dtype, uint32_t flags, int B, int L, int P, int Cin, int Cout, int CoutPad, int taps,
+               const void* x, const void* w, const float* bias, const void* residual, void* y,
+               float* partials_out, void* stream)
+{
+    adk_op o = zero_op(ADK_OP_CONV, dtype);
+    o.flags = flags; o.B = B; o.L = L; o.P = P; o.Cin = Cin; o.Cout = Cout; o.CoutPad = CoutPad; o.taps = taps;
+    o.x = x; o.w = w; o.bias = bias; o.residual = residual; o.y = y; o.partials_out = partials_out;
+    return adk_run_plan(&o, 1, stream);
+}
+
+int adk_gn_apply(int dtype, uint32_t flags, int B, int L, int P, int C, float eps,
+                 const void* x, const float* partials_in, int n_partials_in,
+                 const float* gamma, const float* beta, const void* residual, void* y,
+                 float* partials_out, void* stream)
+{
+    adk_op o = zero_op(ADK_OP_GN_APPLY, dtype);
+    o.flags = flags; o.B = B; o.L = L; o.P = P; o.Cin = C; o.Cout = C; o.f0 = eps;
+    o.x = x; o.partials_in = partials_in; o.n_partials_in = n_partials_in; o.gamma = gamma; o.beta = beta;
+    o.residual = residual; o.y = y; o.partials_out = partials_out;
+    return adk_run_plan(&o, 1, stream);
+}
+
+int adk_gn_stats(int dtype, int B, int L, int P, int C, const void* x, float* partials_out, void* stream)
+{
+    adk_op o = zero_op(ADK_OP_GN_STATS, dtype);
+    o.B = B; o.L = L; o.P = P; o.Cin = C; o.x = x; o.partials_out = partials_out;
+    return adk_run_plan(&o, 1, stream);
+}
+
+static int fir_entry(int kind, int dtype, int B, int L, int P, int C, int K, const float* taps,
+                     const void* x, void* y, void* stream)
+{
+    adk_op o = zero_op(kind, dtype);
+    o.B = B; o.L = L; o.P = P; o.Cin = C; o.taps = K; o.w = taps; o.x = x; o.y = y;
+    return adk_run_plan(&o, 1, stream);
+}
+
+int adk_fir_down2(int dtype, int B, int L, int P, int C, int K, const float* taps, const void* x, void* y, void* stream)
+{
+    return fir_entry(ADK_OP_FIR_DOWN, dtype, B, L, P, C, K, taps, x, y, stream);
+}
+
+int adk_fir_up2(int dtype, int B, int L, int P, int C, int K, const float* taps, const void* x, void* y, void* stream)
+{
+    return fir_entry(ADK_OP_FIR_UP, dtype, B, L, P, C, K, taps, x, y, stream);
+}
+
+int adk_attn1d(int dtype, int B, int L, int P, int C, const void* qkv, void* y, void* stream)
+{
+    adk_op o = zero_op(ADK_OP_ATTN, dtype);
+    o.B = B; o.L = L; o.P = P; o.Cin = C; o.x = qkv; o.y = y;
+    return adk_run_plan(&o, 1, stream);
+}
+
+int adk_pack_input(int dtype, int B, int L, int P, int Cx, const float* x, const float* t,
+                   const int32_t* step, int t_stride, const float* fw, void* y, void* stream)
+{
+    adk_op o = zero_op(ADK_OP_PACK_INPUT, dtype);
+    o.B = B; o.L = L; o.P = P; o.Cin = Cx; o.x = x; o.aux0 = t; o.bias = reinterpret_cast<const float*>(step);
+    o.i0 = t_stride; o.w = fw; o.y = y;
+    return adk_run_plan(&o, 1, stream);
+}
+
+int adk_unpack_output(int B, int L, int P, int C, const float* x, float* y, void* stream)
+{
+    adk_op o = zero_op(ADK_OP_UNPACK_OUTPUT, ADK_F32);
+    o.B = B; o.L = L; o.P = P; o.Cin = C; o.x = x; o.y = y;
+    return adk_run_plan(&o, 1, stream);
+}
+
+int adk_pqmf_analysis(int B, int Ch, int T, int M, int K, const float* x, const float* fwT, float* y, void* stream)
+{
+    adk_op o = zero_op(ADK_OP_PQMF_ANALYSIS, ADK_F32);
+    o.B = B; o.Cin = Ch; o.L = T; o.i0 = M; o.taps = K; o.x = x; o.w = fwT; o.y = y;
+    return adk_run_plan(&o, 1, stream);
+}
+
+int adk_pqmf_synthesis(int B, int Ch, int N, int M, int Kt, const float* x, const float* iwT, float* y, void* stream)
+{
+    adk_op o = zero_op(ADK_OP_PQMF_SYNTHESIS, ADK_F32);
+    o.B = B; o.Cin = Ch; o.L = N; o.i0 = M; o.taps = Kt; o.x = x; o.w = iwT; o.y = y;
+    return adk_run_plan(&o, 1, stream);
+}
+
+int adk_ddim_update(uint32_t flags, int64_t n, float* x, const float* v, const float* noise, float* pred,
+                    const float* coef, const int32_t* step, void* stream)
+{
+    adk_op o = zero_op(ADK_OP_DDIM_UPDATE, ADK_F32);
+    o.flags = flags; o.i0 = (int32_t)(n & 0x7fffffff); o.i1 = (int32_t)(n >> 31);
+    o.y = x; o.x = v; o.residual = noise; o.aux1 = pred; o.aux0 = coef; o.bias = reinterpret_cast<const float*>(step);
+    return adk_run_plan(&o, 1, stream);
+}
+
+int adk_step_advance(int32_t* step, void* stream)
+{
+    adk_op o = zero_op(ADK_OP_STEP_ADVANCE, ADK_F32);
+    o.y = step;
+    return adk_run_plan(&o, 1, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+// Shared device helpers for libadk (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/adk.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// Chunk-plane layout (CPL): rows of 64 bytes = CB channels; see include/adk.h.
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+    static constexpr int CB = 16;   // channels per 64-byte row
+    static constexpr int NV = 4;    // elements per 16-byte piece
+};
+template <> struct ElemTraits<bf16_t> {
+    static constexpr int CB = 32;
+    static constexpr int NV = 8;
+};
+
+struct Geo {            // geometry of one CPL tensor
+    int B, L, P, Lp;    // Lp = L + 2P
+    long long M;        // rows per plane = B * Lp
+};
+__host__ __device__ inline Geo make_geo(int B, int L, int P) {
+    Geo g; g.B = B; g.L = L; g.P = P; g.Lp = L + 2 * P; g.M = (long long)B * g.Lp; return g;
+}
+
+// ---- 16-byte piece <-> float registers -------------------------------------------------------
+__device__ __forceinline__ void piece_to_float(const uint4& p, float (&f)[4], float) {
+    f[0] = __uint_as_float(p.x); f[1] = __uint_as_float(p.y);
+    f[2] = __uint_as_float(p.z); f[3] = __uint_as_float(p.w);
+}
+__device__ __forceinline__ void piece_to_float(const uint4& p, float (&f)[8], bf16_t) {
+    const uint32_t w[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(w[i] << 16);
+        f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    // plain casts: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
+    union { bf16_t h[2]; uint32_t u; } cv;
+    cv.h[0] = (bf16_t)lo; cv.h[1] = (bf16_t)hi;
+    return cv.u;
+}
+__device__ __forceinline__ uint4 float_to_piece(const float (&f)[4], float) {
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+}
+__device__ __forceinline__ uint4 float_to_piece(const float (&f)[8], bf16_t) {
+    return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+}
+
+// ---- deterministic reductions ----------------------------------------------------------------
+template <typename V> __device__ __forceinline__ V wave_sum(V v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block-wide sum of two values with 256 threads; every thread gets the result. `red` = 16 V's of LDS.
+template <typename V> __device__ __forceinline__ void block_sum2(V& a, V& b, V* red) {
+    a = wave_sum(a); b = wave_sum(b);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[2 * w] = a; red[2 * w + 1] = b; }
+    __syncthreads();
+    V sa = 0, sb = 0;
+    for (int i = 0; i < nw; ++i) { sa += red[2 * i]; sb += red[2 * i + 1]; }   // fixed order
+    a = sa; b = sb;
+}
+
+// Finalize GroupNorm(1,C) statistics of sample b from (sum,sumsq) partials, fixed order, in double.
+__device__ __forceinline__ void gn_finalize(const float* __restrict__ partials, int n, double count, float eps,
+                                            float& mean, float& rstd, double* red) {
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { s += (double)partials[2 * i]; q += (double)partials[2 * i + 1]; }
+    block_sum2(s, q, red);
+    const double mu = s / count;
+    double var = q / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean = (float)mu;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// exact GELU (nn.GELU default, approximate='none'): 0.5*x*(1+erf(x/sqrt(2)))
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// XCD-aware bijective remap of a 1-D block id: consecutive logical ids share an XCD (8 XCDs).
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+    const unsigned q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, slot = bid >> 3;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}

@@ -1,0 +1,156 @@
+// Boundary + sampler elementwise kernels (HBM-bound, vectorized).
+//   pack_input   : FourierFeatures(t) -> expand_to_planes -> cat([x, emb]) -> CPL   (reference
+//                  blocks/blocks.py:161-167, decoders/diffusion_decoder.py:144-171)
+//   unpack_output: CPL f32 -> [B,C,L] f32
+//   ddim_update  : literal-order v-DDIM step (reference diffusion/sampling.py:34-52)
+//   step_advance : ++*step, so one captured hipGraph replays every step of the loop
+#include "adk_common.h"
+
+struct PackArgs {
+    const float* x; const float* t; const int32_t* step; const float* fw; void* y;
+    int B, L, P, Lp, Cx, nplanes, t_stride; long long M;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_input_kernel(const PackArgs a)
+{
+    constexpr int NV = ElemTraits<T>::NV, CB = ElemTraits<T>::CB;
+    __shared__ float emb[16];
+    const int plane = blockIdx.y, b = blockIdx.z;
+    if (threadIdx.x < 16) {
+        const float tv = a.step ? a.t[(long long)(*a.step) * a.t_stride] : a.t[b];
+        const int j = threadIdx.x & 7;
+        // 2 * math.pi * input @ weight.T : ((2*pi) * t) * w, each product rounded to f32
+        const float f = __fmul_rn(__fmul_rn(6.283185307179586f, tv), a.fw[j]);
+        emb[threadIdx.x] = threadIdx.x < 8 ? cosf(f) : sinf(f);
+    }
+    __syncthreads();
+    const int r = blockIdx.x * 256 + threadIdx.x;          // row within the sample, halo included
+    if (r >= a.Lp) return;
+    const int l = r - a.P;
+    const bool valid = l >= 0 && l < a.L;
+    unsigned char* yrow = reinterpret_cast<unsigned char*>(a.y) + ((long long)plane * a.M + (long long)b * a.Lp + r) * 64;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float f[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            const int c = plane * CB + q * NV + e;
+            float v = 0.f;
+            if (valid) {
+                if (c < a.Cx) v = a.x[((long long)b * a.Cx + c) * a.L + l];
+                else if (c < a.Cx + 16) v = emb[c - a.Cx];
+            }
+            f[e] = v;
+        }
+        *reinterpret_cast<uint4*>(yrow + q * 16) = float_to_piece(f, T());
+    }
+}
+
+int launch_pack_input(const adk_op& op, hipStream_t st)
+{
+    PackArgs a;
+    a.x = reinterpret_cast<const float*>(op.x); a.t = reinterpret_cast<const float*>(op.aux0);
+    a.step = reinterpret_cast<const int32_t*>(op.bias); a.fw = reinterpret_cast<const float*>(op.w); a.y = op.y;
+    a.B = op.B; a.L = op.L; a.P = op.P; a.Lp = op.L + 2 * op.P; a.Cx = op.Cin; a.t_stride = op.i0;
+    a.M = (long long)op.B * a.Lp;
+    const int Cp = (op.Cin + 16 + 31) / 32 * 32;
+    const int CB = op.dtype == ADK_F32 ? 16 : 32;
+    a.nplanes = Cp / CB;
+    dim3 grid((a.Lp + 255) / 256, a.nplanes, op.B);
+    if (op.dtype == ADK_F32) hipLaunchKernelGGL(pack_input_kernel<float>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(pack_input_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
+}
+
+struct UnpackArgs { const float* x; float* y; int B, L, P, Lp, C; long long M; };
+
+__global__ __launch_bounds__(256) void unpack_output_kernel(const UnpackArgs a)
+{
+    const int l = blockIdx.x * 256 + threadIdx.x, plane = blockIdx.y, b = blockIdx.z;
+    if (l >= a.L) return;
+    const float* row = a.x + ((long long)plane * a.M + (long long)b * a.Lp + a.P + l) * 16;
+    float f[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = reinterpret_cast<const float4*>(row)[q];
+        f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int c = plane * 16 + e;
+        if (c < a.C) a.y[((long long)b * a.C + c) * a.L + l] = f[e];
+    }
+}
+
+int launch_unpack_output(const adk_op& op, hipStream_t st)
+{
+    UnpackArgs a;
+    a.x = reinterpret_cast<const float*>(op.x); a.y = reinterpret_cast<float*>(op.y);
+    a.B = op.B; a.L = op.L; a.P = op.P; a.Lp = op.L + 2 * op.P; a.C = op.Cin; a.M = (long long)op.B * a.Lp;
+    dim3 grid((op.L + 255) / 256, (op.Cin + 15) / 16, op.B);
+    hipLaunchKernelGGL(unpack_output_kernel, grid, dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
+}
+
+// ---- v-DDIM step -------------------------------------------------------------------------------
+struct DdimArgs { float* x; const float* v; const float* noise; float* pred; const float* coef; const int32_t* step; long long n4, n; };
+
+template <bool NOISE>
+__global__ __launch_bounds__(256) void ddim_update_kernel(const DdimArgs a)
+{
+    const float* c = a.coef + (long long)(a.step ? *a.step : 0) * 8;
+    const float alpha = c[1], sigma = c[2], alpha_n = c[3], adj = c[4], dsig = c[5];
+    const bool last = c[6] != 0.f;
+    auto one = [&](float x, float v, float nz, float& pred) -> float {
+        // literal order of sampling.py:34-35,48,52; no FMA contraction so CPU fp32 matches bitwise
+        pred = __fsub_rn(__fmul_rn(x, alpha), __fmul_rn(v, sigma));
+        const float eps = __fadd_rn(__fmul_rn(x, sigma), __fmul_rn(v, alpha));
+        if (last) return x;
+        float xn = __fadd_rn(__fmul_rn(pred, alpha_n), __fmul_rn(eps, adj));
+        if (NOISE) xn = __fadd_rn(xn, __fmul_rn(nz, dsig));
+        return xn;
+    };
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n4; i += stride) {
+        const float4 x = reinterpret_cast<const float4*>(a.x)[i];
+        const float4 v = reinterpret_cast<const float4*>(a.v)[i];
+        float4 nz = make_float4(0, 0, 0, 0);
+        if (NOISE) nz = reinterpret_cast<const float4*>(a.noise)[i];
+        float4 p, xn;
+        xn.x = one(x.x, v.x, nz.x, p.x); xn.y = one(x.y, v.y, nz.y, p.y);
+        xn.z = one(x.z, v.z, nz.z, p.z); xn.w = one(x.w, v.w, nz.w, p.w);
+        reinterpret_cast<float4*>(a.pred)[i] = p;
+        reinterpret_cast<float4*>(a.x)[i] = xn;
+    }
+    // tail (n not a multiple of 4)
+    for (long long i = a.n4 * 4 + (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += stride) {
+        float p;
+        const float xn = one(a.x[i], a.v[i], NOISE ? a.noise[i] : 0.f, p);
+        a.pred[i] = p; a.x[i] = xn;
+    }
+}
+
+int launch_ddim_update(const adk_op& op, hipStream_t st)
+{
+    DdimArgs a;
+    a.x = reinterpret_cast<float*>(op.y); a.v = reinterpret_cast<const float*>(op.x);
+    a.noise = reinterpret_cast<const float*>(op.residual); a.pred = reinterpret_cast<float*>(op.aux1);
+    a.coef = reinterpret_cast<const float*>(op.aux0); a.step = reinterpret_cast<const int32_t*>(op.bias);
+    a.n = ((long long)op.i1 << 31) | (long long)(uint32_t)op.i0;
+    a.n4 = a.n / 4;
+    long long blocks = (a.n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    if (op.flags & ADK_FLAG_NOISE) hipLaunchKernelGGL(ddim_update_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(ddim_update_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
+}
+
+__global__ void step_advance_kernel(int32_t* step) { if (threadIdx.x == 0) step[0] = step[0] + 1; }
+
+int launch_step_advance(const adk_op& op, hipStream_t st)
+{
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<int32_t*>(op.y));
+    return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
+}

@@ -1,0 +1,114 @@
+// GroupNorm(1,C) apply + exact GELU + residual add, one HBM-bound pass over a chunk-plane tensor.
+//
+// Replaces nn.GroupNorm(1,C) -> nn.GELU() -> (+ skip) of ResConvBlock (reference blocks/blocks.py:71-75,
+// 14-15) and the norm of SelfAttention1d (:107,115).  The per-sample statistics arrive as (sum, sumsq)
+// partials written by the producing kernel's epilogue (conv / previous apply), are finalized here in
+// double in a fixed order (bit-reproducible; no atomics), and the pass optionally emits partials of
+// its own output for a following GroupNorm.  16-byte vector loads/stores, per-thread channel slice
+// fixed so gamma/beta live in registers.
+#include "adk_common.h"
+
+struct GnArgs {
+    const void* x; const void* residual; void* y;
+    const float* partials_in; float* partials_out;
+    const float* gamma; const float* beta;       // length >= planes*CB, zero beyond C
+    int B, L, P, Lp; long long M;
+    int n_in; int RB, nrb, nplanes;
+    double count; float eps;
+};
+
+template <typename T, bool GELU, bool APPLY>
+__global__ __launch_bounds__(256) void gn_kernel(const GnArgs a)
+{
+    constexpr int NV = ElemTraits<T>::NV, CB = ElemTraits<T>::CB;
+    __shared__ double red[16];
+    const int rb = blockIdx.x, plane = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, q = tid & 3, r0 = tid >> 2;
+
+    float scale[NV], shift[NV];
+    if (APPLY) {
+        float mean, rstd;
+        gn_finalize(a.partials_in + (long long)b * a.n_in * 2, a.n_in, a.count, a.eps, mean, rstd, red);
+        const int c0 = plane * CB + q * NV;
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+            scale[e] = a.gamma[c0 + e] * rstd;
+            shift[e] = a.beta[c0 + e] - mean * scale[e];
+        }
+    }
+    const long long rowbase = (long long)plane * a.M + (long long)b * a.Lp;
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x) + rowbase * 64 + q * 16;
+    const unsigned char* rbp = a.residual ? reinterpret_cast<const unsigned char*>(a.residual) + rowbase * 64 + q * 16 : nullptr;
+    unsigned char* yb = APPLY ? reinterpret_cast<unsigned char*>(a.y) + rowbase * 64 + q * 16 : nullptr;
+
+    const int lbeg = rb * a.RB, lend = (lbeg + a.RB < a.L) ? lbeg + a.RB : a.L;
+    float s1 = 0.f, s2 = 0.f;
+    for (int l = lbeg + r0; l < lend; l += 64) {
+        const long long ro = (long long)(a.P + l) * 64;
+        float f[NV];
+        piece_to_float(*reinterpret_cast<const uint4*>(xb + ro), f, T());
+        if (APPLY) {
+#pragma unroll
+            for (int e = 0; e < NV; ++e) {
+                float v = f[e] * scale[e] + shift[e];
+                f[e] = GELU ? gelu_erf(v) : v;
+            }
+            if (rbp) {
+                float r[NV];
+                piece_to_float(*reinterpret_cast<const uint4*>(rbp + ro), r, T());
+#pragma unroll
+                for (int e = 0; e < NV; ++e) f[e] += r[e];
+            }
+            *reinterpret_cast<uint4*>(yb + ro) = float_to_piece(f, T());
+        }
+#pragma unroll
+        for (int e = 0; e < NV; ++e) { s1 += f[e]; s2 += f[e] * f[e]; }
+    }
+    if (APPLY && (rb == 0 || rb == a.nrb - 1)) {      // halo rows of the output
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (int r = r0; r < a.P; r += 64) {
+            if (rb == 0) *reinterpret_cast<uint4*>(yb + (long long)r * 64) = z;
+            if (rb == a.nrb - 1) *reinterpret_cast<uint4*>(yb + (long long)(a.P + a.L + r) * 64) = z;
+        }
+    }
+    if (a.partials_out) {
+        float* redf = reinterpret_cast<float*>(red);
+        block_sum2(s1, s2, redf);
+        if (tid == 0) {
+            float* dst = a.partials_out + (((long long)b * a.nplanes + plane) * a.nrb + rb) * 2;
+            dst[0] = s1; dst[1] = s2;
+        }
+    }
+}
+
+static inline int gn_rb(int L) { return L >= 1024 ? 1024 : ((L + 63) / 64) * 64; }
+
+int gn_partials_count(int dtype, int C, int L) {
+    const int CB = dtype == ADK_F32 ? 16 : 32;
+    const int RB = gn_rb(L);
+    return ((C + CB - 1) / CB) * ((L + RB - 1) / RB);
+}
+
+template <typename T>
+static int launch_gn_t(const adk_op& op, hipStream_t st, bool apply)
+{
+    constexpr int CB = ElemTraits<T>::CB;
+    GnArgs a;
+    a.x = op.x; a.residual = op.residual; a.y = op.y;
+    a.partials_in = op.partials_in; a.partials_out = op.partials_out;
+    a.gamma = op.gamma; a.beta = op.beta;
+    a.B = op.B; a.L = op.L; a.P = op.P; a.Lp = op.L + 2 * op.P; a.M = (long long)op.B * a.Lp;
+    a.n_in = op.n_partials_in;
+    a.RB = gn_rb(op.L); a.nrb = (op.L + a.RB - 1) / a.RB; a.nplanes = (op.Cin + CB - 1) / CB;
+    a.count = (double)op.Cin * (double)op.L; a.eps = op.f0;
+    dim3 grid(a.nrb, a.nplanes, op.B);
+    if (!apply) hipLaunchKernelGGL((gn_kernel<T, false, false>), grid, dim3(256), 0, st, a);
+    else if (op.flags & ADK_FLAG_GELU) hipLaunchKernelGGL((gn_kernel<T, true, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gn_kernel<T, false, true>), grid, dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
+}
+
+int launch_gn(const adk_op& op, hipStream_t st, bool apply)
+{
+    return op.dtype == ADK_F32 ? launch_gn_t<float>(op, st, apply) : launch_gn_t<bf16_t>(op, st, apply);
+}

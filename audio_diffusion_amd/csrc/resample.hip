@@ -1,0 +1,117 @@
+// Depthwise FIR x2 down/up-sampling with reflect padding, chunk-plane layout (HBM-bound stencils).
+//
+// Replaces Downsample1d.forward / Upsample1d.forward (reference blocks/blocks.py:191-196, 207-212).  The
+// reference builds a dense diagonal [C,C,K] weight per call and runs a full conv; the result only
+// depends on the K taps, so this is the depthwise stencil:
+//   down: y[lo]   = sum_j k[j] * xr[2*lo + j - (K/2-1)]
+//   up:   y[2m]   = sum_{j odd}  k2[j] * xr[m + (K-1-j)/2 - K/4]
+//         y[2m+1] = sum_{j even} k2[j] * xr[m + (K-j)/2   - K/4]          (k2 = module buffer = 2*table)
+// with xr the reflect extension (index -i -> i, L-1+i -> L-1-i).  Each thread owns a 16-byte channel
+// slice and walks rows, so every global access is a coalesced 64-byte row segment.
+#include "adk_common.h"
+
+struct FirArgs {
+    const void* x; void* y; const float* taps;
+    int B, L, P;          // input geometry
+    int Lo;               // output length
+    int RB, nrb;          // output rows per block
+};
+
+__device__ __forceinline__ int reflect(int i, int L) {
+    i = i < 0 ? -i : i;
+    return i >= L ? 2 * (L - 1) - i : i;
+}
+
+template <typename T, int K, bool UP>
+__global__ __launch_bounds__(256) void fir_kernel(const FirArgs a)
+{
+    constexpr int NV = ElemTraits<T>::NV;
+    const int rb = blockIdx.x, plane = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, q = tid & 3, r0 = tid >> 2;
+    float k[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) k[j] = a.taps[j];
+
+    const int Lpi = a.L + 2 * a.P, Lpo = a.Lo + 2 * a.P;
+    const long long Mi = (long long)a.B * Lpi, Mo = (long long)a.B * Lpo;
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x) +
+                              (((long long)plane * Mi + (long long)b * Lpi + a.P) * 64) + q * 16;
+    unsigned char* yb = reinterpret_cast<unsigned char*>(a.y) + (((long long)plane * Mo + (long long)b * Lpo) * 64) + q * 16;
+
+    if (!UP) {
+        const int lbeg = rb * a.RB, lend = lbeg + a.RB < a.Lo ? lbeg + a.RB : a.Lo;
+        for (int lo = lbeg + r0; lo < lend; lo += 64) {
+            float acc[NV];
+#pragma unroll
+            for (int e = 0; e < NV; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const int li = reflect(2 * lo + j - (K / 2 - 1), a.L);
+                float f[NV];
+                piece_to_float(*reinterpret_cast<const uint4*>(xb + (long long)li * 64), f, T());
+#pragma unroll
+                for (int e = 0; e < NV; ++e) acc[e] += k[j] * f[e];
+            }
+            *reinterpret_cast<uint4*>(yb + (long long)(a.P + lo) * 64) = float_to_piece(acc, T());
+        }
+    } else {
+        // a.RB counts INPUT rows m here; each produces output rows 2m, 2m+1
+        const int mbeg = rb * a.RB, mend = mbeg + a.RB < a.L ? mbeg + a.RB : a.L;
+        for (int m = mbeg + r0; m < mend; m += 64) {
+            float ev[NV], od[NV];
+#pragma unroll
+            for (int e = 0; e < NV; ++e) { ev[e] = 0.f; od[e] = 0.f; }
+#pragma unroll
+            for (int d = -(K / 4); d <= K / 2 - K / 4; ++d) {
+                float f[NV];
+                piece_to_float(*reinterpret_cast<const uint4*>(xb + (long long)reflect(m + d, a.L) * 64), f, T());
+                const int je = K - 1 - 2 * (d + K / 4);     // odd tap feeding y[2m]
+                const int jo = K - 2 * (d + K / 4);         // even tap feeding y[2m+1]
+                if (je >= 0 && je < K) {
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) ev[e] += k[je] * f[e];
+                }
+                if (jo >= 0 && jo < K) {
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) od[e] += k[jo] * f[e];
+                }
+            }
+            *reinterpret_cast<uint4*>(yb + (long long)(a.P + 2 * m) * 64) = float_to_piece(ev, T());
+            *reinterpret_cast<uint4*>(yb + (long long)(a.P + 2 * m + 1) * 64) = float_to_piece(od, T());
+        }
+    }
+    if (rb == 0 || rb == a.nrb - 1) {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (int r = r0; r < a.P; r += 64) {
+            if (rb == 0) *reinterpret_cast<uint4*>(yb + (long long)r * 64) = z;
+            if (rb == a.nrb - 1) *reinterpret_cast<uint4*>(yb + (long long)(a.P + a.Lo + r) * 64) = z;
+        }
+    }
+}
+
+template <typename T, bool UP>
+static int launch_fir_t(const adk_op& op, hipStream_t st)
+{
+    constexpr int CB = ElemTraits<T>::CB;
+    FirArgs a;
+    a.x = op.x; a.y = op.y; a.taps = reinterpret_cast<const float*>(op.w);
+    a.B = op.B; a.L = op.L; a.P = op.P;
+    a.Lo = UP ? op.L * 2 : op.L / 2;
+    const int rows = UP ? op.L : a.Lo;           // loop domain
+    a.RB = rows >= 1024 ? 512 : ((rows + 63) / 64) * 64;
+    a.nrb = (rows + a.RB - 1) / a.RB;
+    dim3 grid(a.nrb, (op.Cin + CB - 1) / CB, op.B);
+    switch (op.taps) {
+        case 4: hipLaunchKernelGGL((fir_kernel<T, 4, UP>), grid, dim3(256), 0, st, a); break;
+        case 8: hipLaunchKernelGGL((fir_kernel<T, 8, UP>), grid, dim3(256), 0, st, a); break;
+        case 12: hipLaunchKernelGGL((fir_kernel<T, 12, UP>), grid, dim3(256), 0, st, a); break;
+        default: return ADK_EINVAL;
+    }
+    return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
+}
+
+int launch_fir(const adk_op& op, hipStream_t st, bool up)
+{
+    if (op.dtype == ADK_F32) return up ? launch_fir_t<float, true>(op, st) : launch_fir_t<float, false>(op, st);
+    return up ? launch_fir_t<bf16_t, true>(op, st) : launch_fir_t<bf16_t, false>(op, st);
+}

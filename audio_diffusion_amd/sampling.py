@@ -1,0 +1,151 @@
+"""v-objective DDIM sampler: drop-in for the reference ``diffusion/sampling.py`` (same names, same
+signatures: ``get_alphas_sigmas``, ``alpha_sigma_to_t``, ``sample(model, x, steps, eta, **extra_args)``).
+
+MI355X design: the per-step scalars (t, alpha, sigma, ...) are computed on the host exactly like the
+reference (CPU fp32 torch ops, sampling.py:22-24,42-44) and uploaded ONCE as a coefficient table; a
+device-side step counter indexes it, so the whole fixed-shape step (denoiser plan + fused literal-order
+update kernel + counter++) is captured in one hipGraph and replayed ``steps`` times with no host work in
+between.  eta > 0 draws its noise with torch's device RNG per step (eager loop).
+"""
+import math
+
+import torch
+
+from . import _lib
+from .unet import DiffusionAttnUnet1D
+
+
+def get_alphas_sigmas(t):
+    """Scaling factors for the clean signal (alpha) and the noise (sigma) at timestep t
+    (reference sampling.py:6-9)."""
+    return torch.cos(t * math.pi / 2), torch.sin(t * math.pi / 2)
+
+
+def alpha_sigma_to_t(alpha, sigma):
+    """Inverse of get_alphas_sigmas (reference sampling.py:11-14)."""
+    return torch.atan2(sigma, alpha) / math.pi * 2
+
+
+def step_coefficients(steps, eta):
+    """Host table [steps, 8] = (t, alpha, sigma, alpha_next, adjusted_sigma, ddim_sigma, is_last, 0),
+    computed with the reference's CPU fp32 expressions (sampling.py:22-24, 42-44)."""
+    t = torch.linspace(1, 0, steps + 1)[:-1]
+    alphas, sigmas = get_alphas_sigmas(t)
+    tab = torch.zeros(steps, 8, dtype=torch.float32)
+    tab[:, 0], tab[:, 1], tab[:, 2] = t, alphas, sigmas
+    for i in range(steps):
+        if i < steps - 1:
+            ddim_sigma = eta * (sigmas[i + 1] ** 2 / sigmas[i] ** 2).sqrt() * \
+                (1 - alphas[i] ** 2 / alphas[i + 1] ** 2).sqrt()
+            adjusted = (sigmas[i + 1] ** 2 - ddim_sigma ** 2).sqrt()
+            tab[i, 3], tab[i, 4], tab[i, 5] = alphas[i + 1], adjusted, ddim_sigma
+        else:
+            tab[i, 6] = 1.0
+    return tab
+
+
+class _FusedSampler:
+    """Captured step loop for one (model, B, T, dtype, steps)."""
+
+    def __init__(self, model, x, steps, dtype, use_graph=True):
+        dev = x.device
+        self.steps = steps
+        self.x = torch.empty_like(x, dtype=torch.float32)
+        self.v = torch.empty_like(self.x)
+        self.pred = torch.empty_like(self.x)
+        self.coef = torch.zeros(steps, 8, dtype=torch.float32, device=dev)
+        self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.plan = model.plan_for(x.shape[0], x.shape[2], dtype, dev,
+                                   t_table=(self.coef.data_ptr(), self.step.data_ptr()))
+        self.plan.bind(self.x.data_ptr(), 0, self.v.data_ptr())
+        tail = (_lib.AdkOp * 2)()
+        n = self.x.numel()
+        tail[0].kind, tail[0].i0, tail[0].i1 = _lib.OP_DDIM_UPDATE, n & 0x7fffffff, n >> 31
+        tail[0].y, tail[0].x, tail[0].aux1 = self.x.data_ptr(), self.v.data_ptr(), self.pred.data_ptr()
+        tail[0].aux0, tail[0].bias = self.coef.data_ptr(), self.step.data_ptr()
+        tail[1].kind, tail[1].y = _lib.OP_STEP_ADVANCE, self.step.data_ptr()
+        self.tail = tail
+        self.graph = None
+        self.use_graph = use_graph
+
+    def _one_step(self, stream_ptr):
+        self.plan.run(stream_ptr)
+        _lib.run_ops(self.tail, 2, stream_ptr)
+
+    def run(self, x, coef_host):
+        self.x.copy_(x)
+        self.coef.copy_(coef_host, non_blocking=False)
+        self.step.zero_()
+        if self.use_graph and self.graph is None:
+            # warm-up step outside capture (module loading), then capture ONE step
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side):
+                self._one_step(side.cuda_stream)
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            torch.cuda.synchronize(x.device)
+            self.x.copy_(x)
+            self.step.zero_()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._one_step(torch.cuda.current_stream(x.device).cuda_stream)
+            self.graph = g
+            # capture does not execute: state is still at step 0
+        if self.graph is not None:
+            for _ in range(self.steps):
+                self.graph.replay()
+        else:
+            sp = torch.cuda.current_stream(x.device).cuda_stream
+            for _ in range(self.steps):
+                self._one_step(sp)
+        return self.pred.clone()
+
+
+@torch.no_grad()
+def sample(model, x, steps, eta, **extra_args):
+    """Draws samples from a model given starting noise (reference sampling.py:16-55).
+
+    Returns the LAST step's ``pred``; ``x`` is not modified; ``randn_like`` is drawn only when ``eta`` is
+    truthy; ``extra_args`` are forwarded to ``model`` (generic path)."""
+    if not x.is_cuda:
+        raise RuntimeError("sample(): MI355X build runs on ROCm devices only; there is no CPU path")
+    if steps < 1:
+        raise ValueError("steps must be >= 1")
+    coef = step_coefficients(steps, eta)
+    x = x.detach().to(torch.float32).contiguous()
+    fused = isinstance(model, DiffusionAttnUnet1D) and not extra_args
+    if fused and not eta:
+        model.check_input(x)
+        dtype = model.resolve_dtype(in_sampler=True)
+        key = ("sampler", x.shape[0], x.shape[2], dtype, str(x.device), steps)
+        smp = model._plans.get(key)
+        if smp is None:
+            smp = _FusedSampler(model, x, steps, dtype, use_graph=getattr(model, "use_graph", True))
+            model._plans[key] = smp
+        return smp.run(x, coef)
+
+    # generic path: any callable model (or eta > 0); the update still runs as one fused kernel
+    lib = _lib.load()
+    dev = x.device
+    coef_d = coef.to(dev)
+    step_d = torch.zeros(1, dtype=torch.int32, device=dev)
+    xs = x.clone()
+    pred = torch.empty_like(xs)
+    ts = xs.new_ones([xs.shape[0]])
+    prev = getattr(model, "compute_dtype", None)
+    auto = isinstance(model, DiffusionAttnUnet1D) and prev is None
+    if auto:
+        model.compute_dtype = torch.bfloat16       # the reference wraps the call in autocast (:30)
+    try:
+        for i in range(steps):
+            v = model(xs, ts * coef[i, 0].item(), **extra_args).float().contiguous()
+            noise = torch.randn_like(xs) if (eta and i < steps - 1) else None
+            sp = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.adk_ddim_update(_lib.FLAG_NOISE if noise is not None else 0, xs.numel(), xs.data_ptr(),
+                                           v.data_ptr(), noise.data_ptr() if noise is not None else None,
+                                           pred.data_ptr(), coef_d.data_ptr(), step_d.data_ptr(), sp), "adk_ddim_update")
+            _lib.check(lib.adk_step_advance(step_d.data_ptr(), sp), "adk_step_advance")
+    finally:
+        if auto:
+            model.compute_dtype = prev
+    return pred

@@ -1,0 +1,507 @@
+"""DiffusionAttnUnet1D: drop-in for the reference denoiser (decoders/diffusion_decoder.py:56-176),
+executed as a flat plan of libadk kernel launches on one HIP stream.
+
+* Same constructor signature/defaults, same ``state_dict`` keys and shapes, same RNG consumption at
+  construction (``torch.manual_seed(s)`` reproduces the reference init bit-for-bit), same
+  ``model(x, t) -> v`` call convention.
+* ``forward`` compiles (once per (batch, length, dtype)) the module tree into an array of ``adk_op``
+  descriptors: packed weights, a statically planned activation arena (no allocation per call, so the
+  step is hipGraph-capturable), chunk-plane activation layout, concat-free SkipBlocks (the two halves
+  of every ``torch.cat([main(x), x])`` are written in place into one buffer by their producers).
+* No CPU or eager fallback: tensors must live on a ROCm device and libadk.so must be present.
+"""
+import ctypes
+from functools import partial
+
+import torch
+from torch import nn
+
+from . import _lib
+from .blocks import (ResConvBlock, SelfAttention1d, SkipBlock, FourierFeatures, Downsample1d, Upsample1d)
+from .pqmf import CachedPQMF
+
+GN_EPS = 1e-5
+
+
+def _ceil_to(x, m):
+    return (x + m - 1) // m * m
+
+
+class _TRef:
+    """A chunk-plane tensor inside the arena: byte offset + logical geometry."""
+    __slots__ = ("off", "C", "L", "f32", "nbytes", "owned")
+
+    def __init__(self, off, C, L, f32, nbytes, owned=True):
+        self.off, self.C, self.L, self.f32, self.nbytes, self.owned = off, C, L, f32, nbytes, owned
+
+
+class _ArenaPlanner:
+    """First-fit offset planner; buffers are released as soon as their last consumer is emitted."""
+
+    def __init__(self, align=256):
+        self.align, self.top, self.holes = align, 0, []
+
+    def alloc(self, n):
+        n = _ceil_to(max(n, 1), self.align)
+        for i, (off, size) in enumerate(self.holes):
+            if size >= n:
+                if size == n:
+                    self.holes.pop(i)
+                else:
+                    self.holes[i] = (off + n, size - n)
+                return off, n
+        off = self.top
+        self.top += n
+        return off, n
+
+    def release(self, off, n):
+        self.holes.append((off, n))
+        self.holes.sort()
+        merged = []
+        for o, s in self.holes:
+            if merged and merged[-1][0] + merged[-1][1] == o:
+                merged[-1] = (merged[-1][0], merged[-1][1] + s)
+            else:
+                merged.append((o, s))
+        if merged and merged[-1][0] + merged[-1][1] == self.top:      # shrink the tail
+            self.top = merged.pop()[0]
+        self.holes = merged
+
+
+class _Plan:
+    """Compiled forward for one (B, T, dtype).  ``ops`` is a ctypes array of adk_op."""
+
+    def __init__(self, model, B, T, dtype, device, t_table=None):
+        self.lib = _lib.load()
+        self.model, self.B, self.T, self.device = model, B, T, device
+        self.dtype = dtype
+        self.adk_dtype = _lib.ADK_F32 if dtype == torch.float32 else _lib.ADK_BF16
+        self.CB = 16 if dtype == torch.float32 else 32
+        self.P = model.kernel_size // 2
+        self.planner = _ArenaPlanner()
+        self.peak = 0
+        self._ops = []            # (AdkOp, {field: ('arena', off) | ('abs', ptr)})
+        self._keep = []           # device tensors that must outlive the plan (weights, tables)
+        self.t_table = t_table
+        self._build()
+        self._finalize()
+
+    # ---- arena helpers -------------------------------------------------------------------
+    def _rows(self, L):
+        return self.B * (L + 2 * self.P)
+
+    def tensor(self, C, L, f32=False):
+        f32 = f32 or self.dtype == torch.float32
+        cb = 16 if f32 else 32
+        nbytes = _ceil_to(C, cb) // cb * self._rows(L) * 64
+        off, n = self.planner.alloc(nbytes)
+        self.peak = max(self.peak, self.planner.top)
+        return _TRef(off, C, L, f32, n)
+
+    def raw(self, nbytes):
+        off, n = self.planner.alloc(nbytes)
+        self.peak = max(self.peak, self.planner.top)
+        return _TRef(off, 0, 0, True, n)
+
+    def half(self, t, which, C):
+        """Channel half of a concat buffer (planes are contiguous, so a half is a byte range)."""
+        cb = 16 if t.f32 else 32
+        assert C % cb == 0, "concat halves must be whole channel chunks"
+        return _TRef(t.off + which * (C // cb) * self._rows(t.L) * 64, C, t.L, t.f32, 0, owned=False)
+
+    def free(self, *ts):
+        for t in ts:
+            if t is not None and t.owned:
+                self.planner.release(t.off, t.nbytes)
+
+    # ---- weights -------------------------------------------------------------------------
+    def _dev(self, key, make):
+        cache = self.model._wcache.setdefault((self.dtype, str(self.device)), {})
+        if key not in cache:
+            cache[key] = make()
+        self._keep.append(cache[key])
+        return cache[key].data_ptr()
+
+    def _packed_conv(self, key, w, cin_alloc, cout_pad):
+        def make():
+            co, ci, k = w.shape
+            wp = torch.zeros(cout_pad, cin_alloc, k, device=self.device, dtype=torch.float32)
+            wp[:co, :ci] = w.detach().to(self.device, torch.float32)
+            wp = wp.view(cout_pad, cin_alloc // self.CB, self.CB, k).permute(1, 3, 0, 2).contiguous()
+            return wp.to(self.dtype)
+        return self._dev(("w", key, cin_alloc, cout_pad), make)
+
+    def _padded_vec(self, key, v, n):
+        def make():
+            out = torch.zeros(n, device=self.device, dtype=torch.float32)
+            out[:v.numel()] = v.detach().to(self.device, torch.float32).reshape(-1)
+            return out
+        return self._dev(("v", key, n), make)
+
+    # ---- op emitters ---------------------------------------------------------------------
+    def _emit(self, kind, ptrs, **fields):
+        op = _lib.AdkOp()
+        op.kind, op.dtype = kind, self.adk_dtype
+        op.B, op.P = self.B, self.P
+        for k, v in fields.items():
+            setattr(op, k, v)
+        self._ops.append((op, ptrs))
+        return op
+
+    def conv(self, x, key, w, bias, Cout, out=None, residual=None, stats=False, out_f32=False):
+        taps = w.shape[2]
+        bn = self.lib.adk_conv_cotile(self.adk_dtype, Cout, x.L)
+        cout_pad = _ceil_to(Cout, bn)
+        cin_alloc = _ceil_to(x.C, 16 if x.f32 else 32)
+        y = out if out is not None else self.tensor(Cout, x.L, f32=out_f32)
+        ptrs = {"x": ("arena", x.off), "y": ("arena", y.off),
+                "w": ("abs", self._packed_conv(key, w, cin_alloc, cout_pad))}
+        if bias is not None:
+            ptrs["bias"] = ("abs", self._padded_vec(key + ".bias", bias, cout_pad))
+        if residual is not None:
+            ptrs["residual"] = ("arena", residual.off)
+        flags = _lib.FLAG_OUT_F32 if (out_f32 and self.dtype != torch.float32) else 0
+        op = self._emit(_lib.OP_CONV, ptrs, flags=flags, L=x.L, Cin=cin_alloc, Cout=Cout, CoutPad=cout_pad, taps=taps)
+        part = None
+        if stats:
+            n = self.lib.adk_partials_count(ctypes.byref(op))
+            part = self.raw(self.B * n * 8)
+            part.C = n
+            ptrs["partials_out"] = ("arena", part.off)
+        return y, part
+
+    def gn_apply(self, x, part, key, gamma, beta, gelu, residual=None, out=None, stats=False):
+        y = out if out is not None else x                     # in place unless told otherwise
+        n = _ceil_to(x.C, 32)
+        ptrs = {"x": ("arena", x.off), "y": ("arena", y.off), "partials_in": ("arena", part.off),
+                "gamma": ("abs", self._padded_vec(key + ".weight", gamma, n)),
+                "beta": ("abs", self._padded_vec(key + ".bias", beta, n))}
+        if residual is not None:
+            ptrs["residual"] = ("arena", residual.off)
+        op = self._emit(_lib.OP_GN_APPLY, ptrs, flags=_lib.FLAG_GELU if gelu else 0, L=x.L, Cin=x.C, Cout=x.C,
+                        n_partials_in=part.C, f0=GN_EPS)
+        pout = None
+        if stats:
+            cnt = self.lib.adk_partials_count(ctypes.byref(op))
+            pout = self.raw(self.B * cnt * 8)
+            pout.C = cnt
+            ptrs["partials_out"] = ("arena", pout.off)
+        return y, pout
+
+    def fir(self, x, key, taps, up, out=None):
+        Lo = x.L * 2 if up else x.L // 2
+        y = out if out is not None else self.tensor(x.C, Lo)
+        ptrs = {"x": ("arena", x.off), "y": ("arena", y.off),
+                "w": ("abs", self._padded_vec(key, taps, taps.numel()))}
+        self._emit(_lib.OP_FIR_UP if up else _lib.OP_FIR_DOWN, ptrs, L=x.L, Cin=x.C, taps=taps.numel())
+        return y
+
+    # ---- module lowering -----------------------------------------------------------------
+    def res_block(self, blk, key, x, out=None, stats=False):
+        """ResConvBlock (reference blocks/blocks.py:66-76,14-15).  Does not free x."""
+        c1, g1, c2 = blk.main[0], blk.main[1], blk.main[3]
+        raw1, p1 = self.conv(x, key + "main.0", c1.weight, c1.bias, blk.c_mid, stats=True)
+        h1, _ = self.gn_apply(raw1, p1, key + "main.1", g1.weight, g1.bias, gelu=True)
+        self.free(p1)
+        has_skip = isinstance(blk.skip, nn.Conv1d)
+        if blk.is_last:
+            if has_skip:
+                r, _ = self.conv(x, key + "skip", blk.skip.weight, None, blk.c_out, out_f32=True)
+            else:   # identity skip into an f32 output: express it as a 1x1 conv with I (rare shape)
+                eye = torch.eye(blk.c_out).unsqueeze(-1)
+                r, _ = self.conv(x, key + "skip.eye", eye, None, blk.c_out, out_f32=True)
+            y, _ = self.conv(h1, key + "main.3", c2.weight, c2.bias, blk.c_out, residual=r, out_f32=True, out=out)
+            self.free(h1, r)
+            return y, None
+        raw2, p2 = self.conv(h1, key + "main.3", c2.weight, c2.bias, blk.c_out, stats=True)
+        self.free(h1)
+        r = x
+        if has_skip:
+            r, _ = self.conv(x, key + "skip", blk.skip.weight, None, blk.c_out)
+        g2 = blk.main[4]
+        y, pout = self.gn_apply(raw2, p2, key + "main.4", g2.weight, g2.bias, gelu=True, residual=r, out=out, stats=stats)
+        self.free(p2)
+        if has_skip:
+            self.free(r)
+        if out is not None:
+            self.free(raw2)
+        return y, pout
+
+    def attention(self, att, key, x, px, out=None):
+        """SelfAttention1d (reference blocks/blocks.py:113-122).  Frees x and px."""
+        n, _ = self.gn_apply(x, px, key + "norm", att.norm.weight, att.norm.bias, gelu=False,
+                             out=self.tensor(x.C, x.L))
+        self.free(px)
+        qkv, _ = self.conv(n, key + "qkv_proj", att.qkv_proj.weight, att.qkv_proj.bias, 3 * x.C)
+        self.free(n)
+        y = self.tensor(x.C, x.L)
+        self._emit(_lib.OP_ATTN, {"x": ("arena", qkv.off), "y": ("arena", y.off)}, L=x.L, Cin=x.C)
+        self.free(qkv)
+        o, _ = self.conv(y, key + "out_proj", att.out_proj.weight, att.out_proj.bias, x.C, residual=x, out=out)
+        self.free(y, x)
+        return o
+
+    def block_chain(self, mods, keys, x, final_out=None):
+        """A run of [ResConvBlock, (SelfAttention1d|Identity)] pairs; frees intermediates and x."""
+        cur = x
+        for j in range(0, len(mods), 2):
+            blk, att = mods[j], mods[j + 1]
+            last_pair = j + 2 >= len(mods)
+            has_att = isinstance(att, SelfAttention1d)
+            y, p = self.res_block(blk, keys[j], cur, stats=has_att,
+                                  out=final_out if (last_pair and not has_att) else None)
+            self.free(cur)
+            cur = y
+            if has_att:
+                cur = self.attention(att, keys[j + 1], cur, p, out=final_out if last_pair else None)
+        return cur
+
+    def level(self, skip, key, cat):
+        """SkipBlock at level >= 2 (reference decoders/diffusion_decoder.py:97-121): its input already sits in
+        the second half of ``cat``; the upsampled main path is written into the first half."""
+        m = skip.main
+        c_prev = cat.C // 2
+        x = self.half(cat, 1, c_prev)
+        d = self.fir(x, key + "0.kernel", m[0].kernel, up=False)
+        inner = m[7]
+        keys = [f"{key}{j}." for j in range(15)]
+        if isinstance(inner, SkipBlock):
+            c = m[1].c_out
+            cat_in = self.tensor(2 * c, d.L)
+            h = self.block_chain(list(m[1:7]), keys[1:7], d, final_out=self.half(cat_in, 1, c))
+            self.level(inner, key + "7.main.", cat_in)
+            h = cat_in
+        else:
+            h = self.block_chain(list(m[1:7]), keys[1:7], d)
+        u = self.block_chain(list(m[8:14]), keys[8:14], h)
+        self.fir(u, key + "14.kernel", m[14].kernel, up=True, out=self.half(cat, 0, c_prev))
+        self.free(u)
+
+    def _build(self):
+        m, B = self.model, self.B
+        bands = m.pqmf_bands
+        L0 = self.T // bands
+        cx = m.io_channels * bands
+        x_ptrs = {"x": ("input", 0)}
+        if bands > 1:
+            fwT, iwT = m.pqmf.packed_filters(self.device)
+            self._keep += [fwT, iwT]
+            ana = self.raw(B * cx * L0 * 4)
+            self._emit(_lib.OP_PQMF_ANALYSIS, {"x": ("input", 0), "w": ("abs", fwT.data_ptr()), "y": ("arena", ana.off)},
+                       Cin=m.io_channels, L=self.T, i0=bands, taps=fwT.shape[0])
+            x_ptrs = {"x": ("arena", ana.off)}
+        x0 = self.tensor(_ceil_to(cx + 16, 32), L0)
+        x0.C = cx + 16
+        fw = self._padded_vec("timestep_embed.weight", m.timestep_embed.weight, 8)
+        ptrs = dict(x_ptrs, w=("abs", fw), y=("arena", x0.off))
+        if self.t_table is None:
+            ptrs["aux0"] = ("t", 0)
+            self._emit(_lib.OP_PACK_INPUT, ptrs, L=L0, Cin=cx)
+        else:
+            coef_ptr, step_ptr = self.t_table
+            ptrs["aux0"], ptrs["bias"] = ("abs", coef_ptr), ("abs", step_ptr)
+            self._emit(_lib.OP_PACK_INPUT, ptrs, L=L0, Cin=cx, i0=8)
+        if bands > 1:
+            self.free(ana)
+
+        net = m.net
+        c1 = net[0].c_out
+        h, _ = self.res_block(net[0], "net.0.", x0)
+        self.free(x0)
+        h2, _ = self.res_block(net[1], "net.1.", h)
+        self.free(h)
+        cat = self.tensor(2 * c1, L0)
+        self.res_block(net[2], "net.2.", h2, out=self.half(cat, 1, c1))
+        self.free(h2)
+        self.level(net[3], "net.3.main.", cat)
+        h, _ = self.res_block(net[4], "net.4.", cat)
+        self.free(cat)
+        h2, _ = self.res_block(net[5], "net.5.", h)
+        self.free(h)
+        o, _ = self.res_block(net[6], "net.6.", h2)
+        self.free(h2)
+        if bands > 1:
+            flat = self.raw(B * cx * L0 * 4)
+            self._emit(_lib.OP_UNPACK_OUTPUT, {"x": ("arena", o.off), "y": ("arena", flat.off)}, L=L0, Cin=cx)
+            self._emit(_lib.OP_PQMF_SYNTHESIS, {"x": ("arena", flat.off), "w": ("abs", iwT.data_ptr()), "y": ("output", 0)},
+                       Cin=m.io_channels, L=L0, i0=bands, taps=iwT.shape[1])
+        else:
+            self._emit(_lib.OP_UNPACK_OUTPUT, {"x": ("arena", o.off), "y": ("output", 0)}, L=L0, Cin=cx)
+
+    def _finalize(self):
+        self.arena = torch.zeros(self.peak + 4096, dtype=torch.uint8, device=self.device)
+        base = self.arena.data_ptr()
+        n = len(self._ops)
+        self.ops = (_lib.AdkOp * n)()
+        self._patch = {"input": [], "output": [], "t": []}
+        for i, (op, ptrs) in enumerate(self._ops):
+            for field, (kind, val) in ptrs.items():
+                if kind == "arena":
+                    setattr(op, field, base + val)
+                elif kind == "abs":
+                    setattr(op, field, val)
+                else:
+                    self._patch[kind].append((i, field))
+            self.ops[i] = op
+        self.n_ops = n
+        del self._ops
+
+    def bind(self, x_ptr, t_ptr, out_ptr):
+        for i, f in self._patch["input"]:
+            setattr(self.ops[i], f, x_ptr)
+        for i, f in self._patch["t"]:
+            setattr(self.ops[i], f, t_ptr)
+        for i, f in self._patch["output"]:
+            setattr(self.ops[i], f, out_ptr)
+
+    def run(self, stream_ptr):
+        _lib.run_ops(self.ops, self.n_ops, stream_ptr)
+
+    def validate(self):
+        """Host-only check of every op descriptor (adk_validate_plan); launches nothing."""
+        unbound = [(i, f) for k in self._patch for (i, f) in self._patch[k] if not getattr(self.ops[i], f)]
+        for i, f in unbound:
+            setattr(self.ops[i], f, 1)
+        try:
+            _lib.check(self.lib.adk_validate_plan(self.ops, self.n_ops), "adk_validate_plan")
+        finally:
+            for i, f in unbound:
+                setattr(self.ops[i], f, None)
+
+
+class DiffusionAttnUnet1D(nn.Module):
+    """Drop-in for the reference class of the same name (decoders/diffusion_decoder.py:56-176)."""
+
+    def __init__(
+        self,
+        io_channels=2,
+        depth=14,
+        n_attn_layers=6,
+        c_mults=[128, 128, 256, 256] + [512] * 10,
+        cond_dim=0,
+        cond_noise_aug=False,
+        pqmf_bands=1,
+        kernel_size=5,
+        learned_resample=False,
+        strides=[2] * 14,
+        conv_bias=True,
+    ):
+        super().__init__()
+        if learned_resample:
+            raise NotImplementedError("learned_resample=True (Downsample1d_2/Upsample1d_2) is not on the MI355X hot path yet")
+        if cond_dim or cond_noise_aug:
+            raise NotImplementedError("conditioning inputs are not on the MI355X hot path yet")
+        if kernel_size != 5:
+            raise NotImplementedError("libadk convolution kernels are built for kernel_size=5")
+        if depth < 2:
+            raise ValueError("depth must be >= 2 (the reference's depth-1 net has mismatched channels)")
+        self.io_channels, self.depth, self.n_attn_layers = io_channels, depth, n_attn_layers
+        self.c_mults = list(c_mults)
+        self.pqmf_bands, self.kernel_size = pqmf_bands, kernel_size
+        self.cond_noise_aug = cond_noise_aug
+
+        # construction order == reference (:80-133): pqmf, timestep_embed, then levels innermost-first
+        if pqmf_bands > 1:
+            self.pqmf = CachedPQMF(2, 70, pqmf_bands)
+        self.timestep_embed = FourierFeatures(1, 16)
+        attn_layer = depth - n_attn_layers - 1
+        conv_block = partial(ResConvBlock, kernel_size=kernel_size, conv_bias=conv_bias)
+        block = nn.Identity()
+        for i in range(depth, 0, -1):
+            c = c_mults[i - 1]
+            if i > 1:
+                c_prev = c_mults[i - 2]
+                add_attn = i >= attn_layer and n_attn_layers > 0
+
+                def attn(ch):
+                    return SelfAttention1d(ch, ch // 32) if add_attn else nn.Identity()
+                mods = [Downsample1d("cubic"), conv_block(c_prev, c, c)]
+                mods += [attn(c), conv_block(c, c, c), attn(c), conv_block(c, c, c), attn(c), block]
+                mods += [conv_block(c * 2 if i != depth else c, c, c), attn(c), conv_block(c, c, c), attn(c)]
+                mods += [conv_block(c, c, c_prev), attn(c_prev), Upsample1d(kernel="cubic")]
+                block = SkipBlock(*mods)
+            else:
+                block = nn.Sequential(
+                    conv_block(io_channels * pqmf_bands + cond_dim + 16, c, c),
+                    conv_block(c, c, c),
+                    conv_block(c, c, c),
+                    block,
+                    conv_block(c * 2, c, c),
+                    conv_block(c, c, c),
+                    conv_block(c, c, io_channels * pqmf_bands, is_last=True),
+                )
+        self.net = block
+        with torch.no_grad():
+            for param in self.net.parameters():
+                param *= 0.5
+
+        self.compute_dtype = None      # None: fp32 for direct calls (bf16 under torch.autocast), bf16 inside sample()
+        self._wcache = {}
+        self._plans = {}
+
+    # ---- cache management ----------------------------------------------------------------
+    def invalidate_cache(self):
+        """Drop packed weights and compiled plans (call after mutating parameters in place)."""
+        self._wcache = {}
+        self._plans = {}
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self.invalidate_cache()
+        return out
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self.invalidate_cache()
+        return out
+
+    # ---- shape checks (raise before anything is launched, like the reference's reflect-pad errors) ----
+    def check_input(self, x):
+        if x.dim() != 3 or x.shape[1] != self.io_channels:
+            raise ValueError(f"expected x of shape [B, {self.io_channels}, T], got {tuple(x.shape)}")
+        T = x.shape[2]
+        if T % self.pqmf_bands:
+            raise ValueError(f"T={T} is not a multiple of pqmf_bands={self.pqmf_bands}")
+        L = T // self.pqmf_bands
+        if L % (1 << (self.depth - 1)):
+            raise ValueError(f"length {L} must be divisible by 2^(depth-1)={1 << (self.depth - 1)}")
+        for i in range(2, self.depth + 1):
+            lin = L >> (i - 2)
+            if lin <= 3:
+                raise RuntimeError(f"level {i}: reflect padding 3 needs an input longer than 3, got {lin} "
+                                   "(input too short for this depth; the reference raises here too)")
+            if (lin >> 1) <= 2:
+                raise RuntimeError(f"level {i}: reflect padding 2 needs an upsample input longer than 2, got {lin >> 1}")
+
+    def resolve_dtype(self, in_sampler=False):
+        if self.compute_dtype is not None:
+            return self.compute_dtype
+        if in_sampler or torch.is_autocast_enabled():
+            return torch.bfloat16
+        return torch.float32
+
+    def plan_for(self, B, T, dtype, device, t_table=None):
+        key = (B, T, dtype, str(device), t_table)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = _Plan(self, B, T, dtype, device, t_table)
+            self._plans[key] = plan
+        return plan
+
+    @torch.no_grad()
+    def forward(self, x, t, cond=None, cond_aug_scale=None):
+        if cond is not None or cond_aug_scale is not None:
+            raise NotImplementedError("conditioning inputs are not on the MI355X hot path yet")
+        if not x.is_cuda:
+            raise RuntimeError("DiffusionAttnUnet1D (MI355X build) runs on ROCm devices only; there is no CPU path")
+        self.check_input(x)
+        dtype = self.resolve_dtype()
+        xin = x.detach().to(torch.float32).contiguous()
+        tin = t.detach().to(device=x.device, dtype=torch.float32).contiguous()
+        if tin.numel() != x.shape[0]:
+            raise ValueError(f"t must have one entry per batch item, got {tuple(t.shape)}")
+        plan = self.plan_for(x.shape[0], x.shape[2], dtype, x.device)
+        out = torch.empty_like(xin)
+        plan.bind(xin.data_ptr(), tin.data_ptr(), out.data_ptr())
+        plan.run(torch.cuda.current_stream(x.device).cuda_stream)
+        return out

@@ -1,0 +1,160 @@
+/*
+ * adk.h — C ABI of libadk.so: the MI355X (gfx950) kernels behind the audio-diffusion sampling
+ * hot path  sample(model, x, steps, eta)  ->  DiffusionAttnUnet1D.forward(x, t).
+ *
+ * The reference has NO FFI/plugin layer for this path (it is 100 % Python on ATen ops), so each
+ * entry point below cites the reference Python call it replaces (paths relative to the reference
+ * checkout).  Conventions for every entry point:
+ *   - plain C: raw DEVICE pointers, ints, floats, a hipStream_t passed as void*; no torch types;
+ *   - returns 0 on success, a negative ADK_E* code otherwise; adk_last_error() gives the text;
+ *   - no ownership transfer, no allocation, no host sync: callers own every buffer (graph-capturable);
+ *   - all launches go to the given stream; arguments are validated on the host BEFORE any launch.
+ *
+ * Activation layout ("chunk-plane", CPL) used by every kernel except the NCL boundary ops:
+ *   element (b, c, l) of a [B, C, L] tensor with halo P lives at
+ *       (((c / CB) * M) + b * Lp + P + l) * CB + (c % CB)        (in elements)
+ *   with Lp = L + 2P, M = B * Lp, CB = 64 bytes / sizeof(elem) (16 for f32, 32 for bf16);
+ *   C is padded up to a multiple of CB (pad channels hold zeros), halo rows hold zeros
+ *   (every producer kernel writes them), so k-tap convolutions read their zero padding from memory.
+ */
+#ifndef ADK_H
+#define ADK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADK_OK 0
+#define ADK_EINVAL (-1)   /* bad argument / unsupported shape (nothing was launched)   */
+#define ADK_ELAUNCH (-2)  /* HIP launch error                                           */
+
+#define ADK_F32 0
+#define ADK_BF16 1
+
+/* op kinds for adk_op / adk_run_plan */
+enum {
+    ADK_OP_CONV = 1,        /* nn.Conv1d k in {1,5}: blocks/blocks.py:70,73 (ResConvBlock), :68 (skip),
+                               :109-110 (qkv_proj/out_proj)                                          */
+    ADK_OP_GN_APPLY = 2,    /* nn.GroupNorm(1,C) [+ nn.GELU] [+ residual add]: blocks/blocks.py:71-75,
+                               :14-15 (ResidualBlock add), :107,115 (attention norm)                 */
+    ADK_OP_GN_STATS = 3,    /* per-sample (sum, sumsq) partials of a CPL tensor (GroupNorm statistics) */
+    ADK_OP_FIR_DOWN = 4,    /* Downsample1d.forward: blocks/blocks.py:191-196                        */
+    ADK_OP_FIR_UP = 5,      /* Upsample1d.forward:   blocks/blocks.py:207-212                        */
+    ADK_OP_ATTN = 6,        /* SelfAttention1d core (softmax(QK^T)V): blocks/blocks.py:116-121       */
+    ADK_OP_PACK_INPUT = 7,  /* FourierFeatures + expand_to_planes + cat: blocks/blocks.py:161-167,
+                               decoders/diffusion_decoder.py:144-171                                 */
+    ADK_OP_UNPACK_OUTPUT = 8, /* CPL f32 -> [B,C,L] f32 (network output boundary)                    */
+    ADK_OP_PQMF_ANALYSIS = 9, /* CachedPQMF.forward: diffusion/pqmf.py:271-283                       */
+    ADK_OP_PQMF_SYNTHESIS = 10, /* CachedPQMF.inverse: diffusion/pqmf.py:285-302                     */
+    ADK_OP_DDIM_UPDATE = 11,  /* per-step v-DDIM update: diffusion/sampling.py:34-52                 */
+    ADK_OP_STEP_ADVANCE = 12  /* device-side step counter ++ (lets one hipGraph replay every step)   */
+};
+
+/* flags */
+#define ADK_FLAG_GELU 1u        /* GN_APPLY: apply exact (erf) GELU after the affine            */
+#define ADK_FLAG_OUT_F32 2u     /* CONV: output (and residual) tensors are f32 CPL even if dtype=bf16 */
+#define ADK_FLAG_NOISE 4u       /* DDIM_UPDATE: add c * noise (eta > 0)                           */
+
+/* One flat descriptor for every op kind; unused fields are 0/NULL.  Field use per kind is
+ * documented at the matching adk_* entry point below (same names). */
+typedef struct adk_op {
+    int32_t kind, dtype;
+    uint32_t flags;
+    int32_t B, L, P;             /* batch, valid length, halo rows of the CPL layout              */
+    int32_t Cin, Cout;           /* logical channel counts                                        */
+    int32_t CoutPad, taps;       /* CONV: rows of the packed weight (multiple of the co-tile), k  */
+    int32_t n_partials_in;       /* GN_APPLY: (sum,sumsq) pairs per sample in partials_in         */
+    int32_t i0, i1, i2;          /* kind-specific ints                                            */
+    float f0, f1;                /* kind-specific floats (eps, scale)                             */
+    const void *x, *w, *bias, *residual;
+    void *y;
+    const float *gamma, *beta, *partials_in;
+    float *partials_out;
+    const void *aux0;
+    void *aux1;
+} adk_op;
+
+int adk_version(void);
+const char *adk_last_error(void);
+
+/* Validate and launch n ops in order on `stream` (one host call per denoiser forward). */
+int adk_run_plan(const adk_op *ops, int n, void *stream);
+
+/* Host-only argument validation of a plan (exactly the checks adk_run_plan performs); launches nothing. */
+int adk_validate_plan(const adk_op *ops, int n);
+
+/* Number of (sum,sumsq) pairs per sample that an op writes to partials_out (0 if none). */
+int adk_partials_count(const adk_op *op);
+
+/* Co-tile (rows of packed weight must be a multiple of this) the conv kernel will use. */
+int adk_conv_cotile(int dtype, int Cout, int L);
+
+/* ---- single-op entry points (thin wrappers that fill an adk_op and call adk_run_plan) ---- */
+
+/* Replaces nn.Conv1d(Cin, Cout, taps, padding=taps//2) (blocks/blocks.py:70,73; 1x1: :68,:109,:110).
+ *   x   CPL [B,Cin,L] halo P (P >= taps/2); w packed [Cin/CB][taps][CoutPad][CB] (dtype);
+ *   bias f32 [CoutPad] or NULL; residual CPL [B,Cout,L] or NULL (added to the result);
+ *   y CPL [B,Cout,L]; partials_out f32 [B][adk_partials_count][2] or NULL (stats of y). */
+int adk_conv1d(int dtype, uint32_t flags, int B, int L, int P, int Cin, int Cout, int CoutPad, int taps,
+               const void *x, const void *w, const float *bias, const void *residual, void *y,
+               float *partials_out, void *stream);
+
+/* Replaces nn.GroupNorm(1,C)(x) [-> nn.GELU()] [+ residual] (blocks/blocks.py:71-75,14-15,107).
+ *   mean/var per sample come from partials_in [B][n_partials_in][2]; y may alias x. */
+int adk_gn_apply(int dtype, uint32_t flags, int B, int L, int P, int C, float eps,
+                 const void *x, const float *partials_in, int n_partials_in,
+                 const float *gamma, const float *beta, const void *residual, void *y,
+                 float *partials_out, void *stream);
+
+/* Per-sample (sum,sumsq) partials of a CPL tensor, for inputs whose producer emitted none. */
+int adk_gn_stats(int dtype, int B, int L, int P, int C, const void *x, float *partials_out, void *stream);
+
+/* Replaces Downsample1d(kernel).forward (blocks/blocks.py:191-196): reflect pad K/2-1, K-tap FIR,
+ * stride 2.  taps f32 [K] (device), K in {4,8,12}; x CPL [B,C,L] -> y CPL [B,C,L/2]. */
+int adk_fir_down2(int dtype, int B, int L, int P, int C, int K, const float *taps,
+                  const void *x, void *y, void *stream);
+
+/* Replaces Upsample1d(kernel).forward (blocks/blocks.py:207-212): taps = 2*table (the module's
+ * buffer), reflect pad, transposed conv stride 2.  x CPL [B,C,L] -> y CPL [B,C,2L]. */
+int adk_fir_up2(int dtype, int B, int L, int P, int C, int K, const float *taps,
+                const void *x, void *y, void *stream);
+
+/* Replaces the attention core of SelfAttention1d.forward (blocks/blocks.py:116-121):
+ *   qkv CPL [B,3C,L] (channel order q-heads,k-heads,v-heads; head dim 32) -> y CPL [B,C,L]. */
+int adk_attn1d(int dtype, int B, int L, int P, int C, const void *qkv, void *y, void *stream);
+
+/* Replaces FourierFeatures + expand_to_planes + torch.cat (blocks/blocks.py:161-167,
+ * decoders/diffusion_decoder.py:144-171):  x f32 [B,Cx,L] (NCL), t: f32 [B] if t_table==0, else
+ * t = ((const float*)t)[*step * stride] broadcast (graph replay); fw f32 [8] (timestep_embed.weight);
+ * y CPL [B, roundup(Cx+16,32), L] = [x | cos(2*pi*t*fw) | sin(2*pi*t*fw) | 0...]. */
+int adk_pack_input(int dtype, int B, int L, int P, int Cx, const float *x, const float *t,
+                   const int32_t *step, int t_stride, const float *fw, void *y, void *stream);
+
+/* CPL f32 [B,C,L] -> NCL f32 [B,C,L] (output boundary of the network). */
+int adk_unpack_output(int B, int L, int P, int C, const float *x, float *y, void *stream);
+
+/* Replaces CachedPQMF.forward (diffusion/pqmf.py:271-283).  x f32 [B,Ch,T]; fwT f32 [K][M] = the
+ * forward_conv weight transposed (K odd, zero padding K/2 each side, stride M); y f32 [B,Ch*M,T/M]. */
+int adk_pqmf_analysis(int B, int Ch, int T, int M, int K, const float *x, const float *fwT, float *y,
+                      void *stream);
+
+/* Replaces CachedPQMF.inverse (diffusion/pqmf.py:285-302).  x f32 [B,Ch*M,N]; iwT f32 [M(c)][Kt][M(m)]
+ * = inverse_conv weight permuted (m fastest); y f32 [B,Ch,N*M]. */
+int adk_pqmf_synthesis(int B, int Ch, int N, int M, int Kt, const float *x, const float *iwT, float *y,
+                       void *stream);
+
+/* Replaces the body of the sampling loop after the model call (diffusion/sampling.py:34-52), literal
+ * operation order, for step i = *step:  coef f32 [steps][8] = {t, alpha, sigma, alpha_next, adjusted_sigma,
+ * ddim_sigma, is_last, 0}.  pred = x*alpha - v*sigma; eps = x*sigma + v*alpha;
+ * if !is_last: x = pred*alpha_next + eps*adjusted (+ noise*ddim_sigma).  x updated in place. */
+int adk_ddim_update(uint32_t flags, int64_t n, float *x, const float *v, const float *noise, float *pred,
+                    const float *coef, const int32_t *step, void *stream);
+
+int adk_step_advance(int32_t *step, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADK_H */

@@ -1,0 +1,345 @@
+"""GPU parity tests, one libadk entry point at a time, called through the C ABI (ctypes on raw device
+pointers).  Reference = plain PyTorch fp32 ops on the CPU (the same ATen kernels the reference runs) or
+the golden vectors captured from the imported reference.
+
+Tolerances (scale-relative max error, conftest.rel_err): f32 kernels 1e-5 (north_star budget: 1e-4 per
+whole denoiser call), bf16 kernels 1.5e-2 on a single op (inputs/outputs rounded to 8 mantissa bits).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err, sub_sd
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": (torch.float32, 0, 1e-5), "bf16": (torch.bfloat16, 1, 1.5e-2)}
+
+
+@pytest.fixture(scope="module")
+def env():
+    from audio_diffusion_amd import _lib, layout
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    lib = _lib.load()
+    return lib, _lib, layout, torch.device("cuda:0")
+
+
+def sp():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def pack_w(w, cin_alloc, cout_pad, cb, dtype, dev):
+    co, ci, k = w.shape
+    wp = torch.zeros(cout_pad, cin_alloc, k)
+    wp[:co, :ci] = w
+    return wp.view(cout_pad, cin_alloc // cb, cb, k).permute(1, 3, 0, 2).contiguous().to(dev, dtype)
+
+
+def quant(x, dtype):
+    return x.to(dtype).float()
+
+
+CONV_CASES = [
+    # B, L, Cin, Cout, taps, bias, residual
+    (2, 256, 32, 128, 5, True, False),
+    (2, 200, 64, 96, 5, True, False),      # ragged L (masked tile), Cout not a tile multiple
+    (3, 64, 128, 128, 5, True, True),      # BM=64 variant
+    (2, 8, 64, 128, 5, True, False),       # BM=32 variant, L < halo-extended tile
+    (2, 24, 96, 64, 1, False, True),       # 1x1, no bias, residual
+    (2, 384, 256, 2, 5, True, False),      # narrow-output variant (co tile 32)
+    (1, 1024, 32, 32, 1, True, False),
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv1d(env, dt, case):
+    lib, _lib, layout, dev = env
+    dtype, adk, tol = DT[dt]
+    B, L, Cin, Cout, taps, has_bias, has_res = case
+    P = 2
+    cb = layout.chunk(dtype)
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(B, Cin, L, generator=g)
+    w = torch.randn(Cout, Cin, taps, generator=g) / (Cin * taps) ** 0.5
+    bias = torch.randn(Cout, generator=g) if has_bias else None
+    res = torch.randn(B, Cout, L, generator=g) if has_res else None
+    xq, wq = quant(x, dtype), quant(w, dtype)
+    ref = F.conv1d(xq, wq, bias, padding=taps // 2)
+    if has_res:
+        ref = ref + quant(res, dtype)
+    bn = lib.adk_conv_cotile(adk, Cout, L)
+    cout_pad = (Cout + bn - 1) // bn * bn
+    cin_alloc = (Cin + cb - 1) // cb * cb
+    xd = layout.to_cpl(x.to(dev), dtype, P)
+    wd = pack_w(w, cin_alloc, cout_pad, cb, dtype, dev)
+    bd = None
+    if has_bias:
+        bd = torch.zeros(cout_pad, device=dev)
+        bd[:Cout] = bias.to(dev)
+    rd = layout.to_cpl(res.to(dev), dtype, P) if has_res else None
+    planes_out = (Cout + cb - 1) // cb
+    yd = torch.full((planes_out, B, L + 2 * P, cb), 7.0, dtype=dtype, device=dev)   # poison incl. halo
+    op = _lib.AdkOp()
+    op.kind, op.dtype, op.L, op.Cout, op.CoutPad, op.Cin = _lib.OP_CONV, adk, L, Cout, cout_pad, cin_alloc
+    npart = lib.adk_partials_count(C.byref(op))
+    part = torch.zeros(B, npart, 2, device=dev)
+    rc = lib.adk_conv1d(adk, 0, B, L, P, cin_alloc, Cout, cout_pad, taps, xd.data_ptr(), wd.data_ptr(),
+                        bd.data_ptr() if bd is not None else None, rd.data_ptr() if rd is not None else None,
+                        yd.data_ptr(), part.data_ptr(), sp())
+    assert rc == 0, lib.adk_last_error()
+    torch.cuda.synchronize()
+    full = layout.from_cpl(yd, planes_out * cb).cpu()
+    y = full[:, :Cout, P:P + L]
+    assert rel_err(y, ref) <= tol
+    assert float(full[:, :, :P].abs().max()) == 0.0 and float(full[:, :, P + L:].abs().max()) == 0.0, "halo rows not zero"
+    assert float(full[:, Cout:].abs().max() if full.shape[1] > Cout else 0.0) == 0.0, "pad channels not zero"
+    # (sum, sumsq) partials describe the stored tensor (pre-rounding values in the bf16 path)
+    s = part.double().sum(1).cpu()
+    ref64 = ref.double()
+    scale = ref64.abs().sum((1, 2))
+    assert float(((s[:, 0] - ref64.sum((1, 2))).abs() / scale).max()) <= 1e-4
+    assert float(((s[:, 1] - ref64.pow(2).sum((1, 2))).abs() / ref64.pow(2).sum((1, 2))).max()) <= 1e-4
+
+
+def test_conv1d_rejects_bad_shapes(env):
+    lib, _lib, layout, dev = env
+    buf = torch.zeros(1 << 16, device=dev)
+    p = buf.data_ptr()
+    assert lib.adk_conv1d(0, 0, 1, 64, 2, 20, 32, 32, 5, p, p, None, None, p, None, sp()) == -1   # Cin not chunked
+    assert b"Cin" in lib.adk_last_error()
+    assert lib.adk_conv1d(0, 0, 1, 64, 1, 32, 32, 32, 5, p, p, None, None, p, None, sp()) == -1   # halo < taps/2
+    assert lib.adk_conv1d(0, 0, 1, 64, 2, 32, 32, 32, 3, p, p, None, None, p, None, sp()) == -1   # taps
+    assert lib.adk_conv1d(0, 0, 1, 64, 2, 32, 64, 64, 5, p, p, None, None, p, None, sp()) == -1   # CoutPad % 128
+    assert lib.adk_conv1d(0, 0, 1, 64, 2, 32, 32, 32, 5, None, p, None, None, p, None, sp()) == -1
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("B,C,L,gelu,res", [(2, 64, 1500, True, True), (3, 96, 40, False, False), (1, 32, 4096, True, False)])
+def test_gn_apply_and_stats(env, dt, B, C, L, gelu, res):
+    lib, _lib, layout, dev = env
+    dtype, adk, tol = DT[dt]
+    P = 2
+    cb = layout.chunk(dtype)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, L, generator=g) * 1.7 + 0.3
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    r = torch.randn(B, C, L, generator=g) if res else None
+    xq = quant(x, dtype)
+    ref = F.group_norm(xq, 1, gamma, beta, 1e-5)
+    if gelu:
+        ref = F.gelu(ref)
+    if res:
+        ref = ref + quant(r, dtype)
+    xd = layout.to_cpl(x.to(dev), dtype, P)
+    op = _lib.AdkOp()
+    op.kind, op.dtype, op.L, op.Cin = _lib.OP_GN_STATS, adk, L, C
+    n = lib.adk_partials_count(C_byref(op))
+    part = torch.zeros(B, n, 2, device=dev)
+    assert lib.adk_gn_stats(adk, B, L, P, C, xd.data_ptr(), part.data_ptr(), sp()) == 0, lib.adk_last_error()
+    torch.cuda.synchronize()
+    s = part.double().sum(1).cpu()
+    assert torch.allclose(s[:, 0], xq.double().sum((1, 2)), rtol=1e-5, atol=1e-2)
+    assert torch.allclose(s[:, 1], xq.double().pow(2).sum((1, 2)), rtol=1e-5)
+    cpad = (C + 31) // 32 * 32
+    gd, bd = torch.zeros(cpad, device=dev), torch.zeros(cpad, device=dev)
+    gd[:C], bd[:C] = gamma.to(dev), beta.to(dev)
+    rd = layout.to_cpl(r.to(dev), dtype, P) if res else None
+    yd = torch.full_like(xd, 3.0)
+    pout = torch.zeros(B, n, 2, device=dev)
+    rc = lib.adk_gn_apply(adk, _lib.FLAG_GELU if gelu else 0, B, L, P, C, 1e-5, xd.data_ptr(), part.data_ptr(), n,
+                          gd.data_ptr(), bd.data_ptr(), rd.data_ptr() if res else None, yd.data_ptr(), pout.data_ptr(), sp())
+    assert rc == 0, lib.adk_last_error()
+    torch.cuda.synchronize()
+    full = layout.from_cpl(yd, yd.shape[0] * cb).cpu()
+    assert rel_err(full[:, :C, P:P + L], ref) <= tol
+    assert float(full[:, :, :P].abs().max()) == 0.0 and float(full[:, :, P + L:].abs().max()) == 0.0
+    so = pout.double().sum(1).cpu()
+    assert torch.allclose(so[:, 0], ref.double().sum((1, 2)), rtol=5e-3, atol=5e-3 * ref.abs().sum((1, 2)).max().item())
+    assert torch.allclose(so[:, 1], ref.double().pow(2).sum((1, 2)), rtol=5e-3)
+    # in place (y aliases x) gives the same bits
+    rc = lib.adk_gn_apply(adk, _lib.FLAG_GELU if gelu else 0, B, L, P, C, 1e-5, xd.data_ptr(), part.data_ptr(), n,
+                          gd.data_ptr(), bd.data_ptr(), rd.data_ptr() if res else None, xd.data_ptr(), None, sp())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(xd[:, :, P:P + L], yd[:, :, P:P + L])
+
+
+def C_byref(op):
+    return C.byref(op)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("kern", ["linear", "cubic", "lanczos3"])
+@pytest.mark.parametrize("L", [8, 16, 4096])
+def test_fir_resamplers_vs_golden(env, golden_blocks, dt, kern, L):
+    lib, _lib, layout, dev = env
+    dtype, adk, tol = DT[dt]
+    z = golden_blocks
+    P = 2
+    for d in ("down", "up"):
+        if f"{d}_{kern}_{L}/x" not in z.files:
+            continue
+        x = torch.from_numpy(z[f"{d}_{kern}_{L}/x"])
+        ref = torch.from_numpy(z[f"{d}_{kern}_{L}/y"])
+        taps = torch.from_numpy(z[f"{d}_{kern}/kernel"]).to(dev)
+        B, Cc, _ = x.shape
+        xd = layout.to_cpl(x.to(dev), dtype, P)
+        Lo = ref.shape[2]
+        yd = torch.full((xd.shape[0], B, Lo + 2 * P, xd.shape[3]), 5.0, dtype=dtype, device=dev)
+        fn = lib.adk_fir_down2 if d == "down" else lib.adk_fir_up2
+        assert fn(adk, B, L, P, Cc, taps.numel(), taps.data_ptr(), xd.data_ptr(), yd.data_ptr(), sp()) == 0, lib.adk_last_error()
+        torch.cuda.synchronize()
+        full = layout.from_cpl(yd, Cc).cpu()
+        if dt == "bf16":     # compare against the stencil of the rounded input
+            from oracle import unet_oracle as U
+            xq = quant(x, dtype)
+            ref = U.downsample_fir(xq, taps.cpu()) if d == "down" else U.upsample_fir(xq, taps.cpu())
+        assert rel_err(full[:, :, P:P + Lo], ref) <= tol
+        assert float(full[:, :, :P].abs().max()) == 0.0 and float(full[:, :, P + Lo:].abs().max()) == 0.0
+
+
+def test_fir_rejects_short_input(env):
+    lib, _lib, layout, dev = env
+    buf = torch.zeros(4096, device=dev)
+    p = buf.data_ptr()
+    # reference: F.pad(reflect) raises when pad >= length (cubic down: pad 3; up: pad 2)
+    assert lib.adk_fir_down2(0, 1, 2, 2, 16, 8, p, p, p, sp()) == -1
+    assert b"reflect" in lib.adk_last_error()
+    assert lib.adk_fir_up2(0, 1, 2, 2, 16, 8, p, p, p, sp()) == -1
+    assert lib.adk_fir_down2(0, 1, 16, 2, 16, 6, p, p, p, sp()) == -1
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("s", [8, 64, 256])
+def test_attention_vs_golden(env, golden_blocks, dt, s):
+    """Whole SelfAttention1d = gn_stats + gn_apply + conv1x1 + attn1d + conv1x1(+residual) vs the reference module."""
+    lib, _lib, layout, dev = env
+    dtype, adk, tol = DT[dt]
+    z = golden_blocks
+    sd = sub_sd(z, f"attn{s}/sd/")
+    x = torch.from_numpy(z[f"attn{s}/x"])
+    ref = torch.from_numpy(z[f"attn{s}/y"])
+    B, Cc, L = x.shape
+    P, cb = 2, layout.chunk(dtype)
+    xd = layout.to_cpl(x.to(dev), dtype, P)
+    op = _lib.AdkOp()
+    op.kind, op.dtype, op.L, op.Cin = _lib.OP_GN_STATS, adk, L, Cc
+    n = lib.adk_partials_count(C.byref(op))
+    part = torch.zeros(B, n, 2, device=dev)
+    assert lib.adk_gn_stats(adk, B, L, P, Cc, xd.data_ptr(), part.data_ptr(), sp()) == 0
+    gd, bd = sd["norm.weight"].to(dev), sd["norm.bias"].to(dev)
+    nd = torch.empty_like(xd)
+    assert lib.adk_gn_apply(adk, 0, B, L, P, Cc, 1e-5, xd.data_ptr(), part.data_ptr(), n, gd.data_ptr(), bd.data_ptr(),
+                            None, nd.data_ptr(), None, sp()) == 0
+    wq = pack_w(sd["qkv_proj.weight"], Cc, 3 * Cc if 3 * Cc % 128 == 0 else (3 * Cc + 127) // 128 * 128, cb, dtype, dev)
+    cp = wq.shape[2]
+    bq = torch.zeros(cp, device=dev)
+    bq[:3 * Cc] = sd["qkv_proj.bias"].to(dev)
+    qkv = torch.empty(3 * Cc // cb, B, L + 2 * P, cb, dtype=dtype, device=dev)
+    assert lib.adk_conv1d(adk, 0, B, L, P, Cc, 3 * Cc, cp, 1, nd.data_ptr(), wq.data_ptr(), bq.data_ptr(), None,
+                          qkv.data_ptr(), None, sp()) == 0, lib.adk_last_error()
+    yd = torch.empty_like(xd)
+    assert lib.adk_attn1d(adk, B, L, P, Cc, qkv.data_ptr(), yd.data_ptr(), sp()) == 0, lib.adk_last_error()
+    wo = pack_w(sd["out_proj.weight"], Cc, 128, cb, dtype, dev)
+    bo = torch.zeros(128, device=dev)
+    bo[:Cc] = sd["out_proj.bias"].to(dev)
+    od = torch.empty_like(xd)
+    assert lib.adk_conv1d(adk, 0, B, L, P, Cc, Cc, 128, 1, yd.data_ptr(), wo.data_ptr(), bo.data_ptr(), xd.data_ptr(),
+                          od.data_ptr(), None, sp()) == 0, lib.adk_last_error()
+    torch.cuda.synchronize()
+    y = layout.from_cpl(od, Cc).cpu()[:, :, P:P + L]
+    assert rel_err(y, ref) <= (1e-5 if dt == "f32" else 2e-2)
+
+
+PQMF_CASES = [(1, 70, 32), (2, 70, 32), (2, 70, 4), (2, 70, 16), (2, 100, 32)]
+
+
+@pytest.mark.parametrize("ch,att,M", PQMF_CASES)
+def test_pqmf_vs_golden(env, golden_pqmf, ch, att, M):
+    lib, _lib, layout, dev = env
+    z = golden_pqmf
+    tag = f"pqmf_c{ch}_a{att}_m{M}"
+    x = torch.from_numpy(z[f"{tag}/x"]).to(dev)
+    fw = torch.from_numpy(z[f"{tag}/fw"]).to(dev)
+    iw = torch.from_numpy(z[f"{tag}/iw"]).to(dev)
+    B, _, T = x.shape
+    N = T // M
+    fwT = fw[:, 0, :].t().contiguous()
+    iwT = iw.permute(1, 2, 0).contiguous()
+    y = torch.empty(B, ch * M, N, device=dev)
+    assert lib.adk_pqmf_analysis(B, ch, T, M, fwT.shape[0], x.data_ptr(), fwT.data_ptr(), y.data_ptr(), sp()) == 0, lib.adk_last_error()
+    r = torch.empty(B, ch, T, device=dev)
+    assert lib.adk_pqmf_synthesis(B, ch, N, M, iwT.shape[1], y.data_ptr(), iwT.data_ptr(), r.data_ptr(), sp()) == 0, lib.adk_last_error()
+    torch.cuda.synchronize()
+    assert rel_err(y, torch.from_numpy(z[f"{tag}/y"])) <= 1e-5
+    assert rel_err(r, torch.from_numpy(z[f"{tag}/z"])) <= 1e-5
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_pack_unpack(env, golden_blocks, dt):
+    lib, _lib, layout, dev = env
+    dtype, adk, _ = DT[dt]
+    z = golden_blocks
+    fw = torch.from_numpy(z["fourier/weight"]).reshape(-1).to(dev)
+    t = torch.from_numpy(z["fourier/t"]).to(dev)
+    emb = torch.from_numpy(z["fourier/y"])
+    B, L, P, Cx = 4, 300, 2, 2
+    x = torch.randn(B, Cx, L)
+    cb = layout.chunk(dtype)
+    yd = torch.full((32 // cb, B, L + 2 * P, cb), 9.0, dtype=dtype, device=dev)
+    assert lib.adk_pack_input(adk, B, L, P, Cx, x.to(dev).data_ptr(), t.data_ptr(), None, 0, fw.data_ptr(), yd.data_ptr(), sp()) == 0
+    torch.cuda.synchronize()
+    full = layout.from_cpl(yd, 32).cpu()
+    assert torch.equal(full[:, :Cx, P:P + L], quant(x, dtype))
+    planes = full[:, Cx:Cx + 16, P:P + L]
+    assert rel_err(planes, emb[:, :, None].expand(-1, -1, L)) <= (2e-6 if dt == "f32" else 4e-3)
+    assert float(full[:, Cx + 16:].abs().max()) == 0.0
+    assert float(full[:, :, :P].abs().max()) == 0.0 and float(full[:, :, P + L:].abs().max()) == 0.0
+    # unpack (f32 CPL -> NCL)
+    src = torch.randn(3, 20, 77)
+    sdv = layout.to_cpl(src.to(dev), torch.float32, P)
+    out = torch.empty(3, 20, 77, device=dev)
+    assert lib.adk_unpack_output(3, 77, P, 20, sdv.data_ptr(), out.data_ptr(), sp()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), src)
+
+
+@pytest.mark.parametrize("eta", [0.0, 0.7])
+def test_ddim_update_bit_exact(env, eta):
+    """Literal operation order of sampling.py:34-52 => bitwise equal to the CPU fp32 result."""
+    lib, _lib, layout, dev = env
+    from audio_diffusion_amd import step_coefficients
+    steps = 7
+    coef = step_coefficients(steps, eta)
+    n = 2 * 2 * 1003            # not a multiple of 4: exercises the scalar tail
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, generator=g)
+    xd = x.to(dev)
+    pred_d = torch.empty(n, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    coef_d = coef.to(dev)
+    t, alphas, sigmas = coef[:, 0], coef[:, 1], coef[:, 2]
+    for i in range(steps):
+        v = torch.randn(n, generator=g)
+        nz = torch.randn(n, generator=g)
+        pred = x * alphas[i] - v * sigmas[i]
+        eps = x * sigmas[i] + v * alphas[i]
+        if i < steps - 1:
+            ddim_sigma = eta * (sigmas[i + 1] ** 2 / sigmas[i] ** 2).sqrt() * (1 - alphas[i] ** 2 / alphas[i + 1] ** 2).sqrt()
+            adjusted = (sigmas[i + 1] ** 2 - ddim_sigma ** 2).sqrt()
+            x = pred * alphas[i + 1] + eps * adjusted
+            if eta:
+                x = x + nz * ddim_sigma
+        vd, nd = v.to(dev), nz.to(dev)
+        flags = _lib.FLAG_NOISE if (eta and i < steps - 1) else 0
+        assert lib.adk_ddim_update(flags, n, xd.data_ptr(), vd.data_ptr(), nd.data_ptr() if flags else None,
+                                   pred_d.data_ptr(), coef_d.data_ptr(), step.data_ptr(), sp()) == 0, lib.adk_last_error()
+        assert lib.adk_step_advance(step.data_ptr(), sp()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(pred_d.cpu(), pred), f"pred differs at step {i}"
+        assert torch.equal(xd.cpu(), x), f"x differs at step {i}"
+    assert int(step.item()) == steps

@@ -1,0 +1,153 @@
+"""CPU: host logic of the product package (no kernels are launched): C-ABI surface, state_dict / init
+parity with the reference, plan compilation + host-side validation, sampler coefficient tables."""
+import ctypes
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, GOLDEN, load_npz, sub_sd
+
+import audio_diffusion_amd as A
+from audio_diffusion_amd import _lib
+from audio_diffusion_amd.unet import _Plan, _ArenaPlanner
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "adk.h")).read()
+    declared = set(re.findall(r"\b(adk_[a-z0-9_]+)\s*\(", header))
+    declared.discard("adk_op")
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libadk.so lacks {name}"
+    assert set(_lib.EXPORTS) == declared
+    assert lib.adk_version() >= 100
+
+
+def test_adk_op_struct_size_matches_c():
+    # 14 int32 + 2 float = 64 bytes, then 11 pointers
+    assert ctypes.sizeof(_lib.AdkOp) == 64 + 11 * 8
+
+
+def test_validation_messages_without_gpu():
+    lib = _lib.load()
+    op = _lib.AdkOp()
+    op.kind = 99
+    assert lib.adk_validate_plan(ctypes.byref(op), 1) == -1
+    assert b"unknown op kind" in lib.adk_last_error()
+    op.kind, op.dtype, op.B, op.L, op.P, op.Cin, op.taps = _lib.OP_FIR_DOWN, 0, 1, 2, 2, 16, 8
+    op.x = op.y = op.w = 1
+    assert lib.adk_validate_plan(ctypes.byref(op), 1) == -1
+    assert b"reflect" in lib.adk_last_error()
+
+
+def test_full_model_init_matches_reference_digest():
+    d = json.load(open(os.path.join(GOLDEN, "full_digest.json")))
+    torch.manual_seed(0)
+    m = A.DiffusionAttnUnet1D(n_attn_layers=4)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(d["tensors"].keys())
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        assert list(v.shape) == d["tensors"][k]["shape"], k
+        h.update(k.encode())
+        h.update(v.contiguous().numpy().tobytes())
+    assert h.hexdigest() == d["meta"]["sd_sha256"]
+    assert sum(p.numel() for p in m.parameters()) == d["meta"]["n_params"] == 221389322
+    # plan for config 1 compiles and passes host validation (CPU dry run: nothing is launched)
+    plan = _Plan(m, 1, 65536, torch.bfloat16, torch.device("cpu"))
+    plan.validate()
+    kinds = [plan.ops[i].kind for i in range(plan.n_ops)]
+    assert kinds.count(_lib.OP_ATTN) == 36 and kinds.count(_lib.OP_FIR_DOWN) == 13 and kinds.count(_lib.OP_FIR_UP) == 13
+    assert kinds.count(_lib.OP_GN_APPLY) == 203
+    assert kinds.count(_lib.OP_CONV) == 259          # 168 k=5 + 19 skips + 72 qkv/out projections
+
+
+@pytest.mark.parametrize("name", ["tiny_d3.npz", "tiny_d5.npz", "tiny_d3_pqmf4.npz", "tiny_d4_noattn_nobias.npz"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_tiny_models_load_and_plan(name, dtype):
+    z = load_npz(name)
+    cfg = json.loads(bytes(z["cfg"]).decode())
+    torch.manual_seed(int(z["seed"]))
+    m = A.DiffusionAttnUnet1D(**cfg)
+    ref_sd = sub_sd(z, "sd/")
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ref_sd.keys())
+    for k in sd:                      # same seed => same init as the reference, bit for bit
+        if k.startswith("pqmf.") and k != "pqmf.h" and not k.endswith("hk"):
+            assert torch.allclose(sd[k], ref_sd[k], rtol=0, atol=1e-6), k
+        elif k.startswith("pqmf."):
+            assert torch.allclose(sd[k], ref_sd[k], rtol=0, atol=1e-6), k
+        else:
+            assert torch.equal(sd[k], ref_sd[k]), k
+    m.load_state_dict(ref_sd, strict=True)
+    B, _, T = z["x"].shape
+    plan = _Plan(m, B, T, dtype, torch.device("cpu"))
+    plan.validate()
+    assert plan.peak > 0
+    with pytest.raises(RuntimeError):
+        m(torch.from_numpy(z["x"]), torch.from_numpy(z["t"]))     # CPU tensors: loud failure, no fallback
+
+
+def test_ctor_errors_mirror_reference():
+    with pytest.raises(ZeroDivisionError):          # attention on C < 32 (blocks/blocks.py:106)
+        A.DiffusionAttnUnet1D(depth=3, c_mults=[16, 16, 16], n_attn_layers=1)
+    with pytest.raises(NotImplementedError):
+        A.DiffusionAttnUnet1D(learned_resample=True)
+    m = A.DiffusionAttnUnet1D(depth=3, c_mults=[32, 32, 64], n_attn_layers=1)
+    with pytest.raises(RuntimeError):
+        m.check_input(torch.zeros(1, 2, 8))
+    with pytest.raises(ValueError):
+        m.check_input(torch.zeros(1, 2, 1026))
+
+
+def test_arena_planner_reuses_and_never_overlaps():
+    import random
+    rnd = random.Random(0)
+    pl = _ArenaPlanner()
+    live = {}
+    for step in range(2000):
+        if live and rnd.random() < 0.45:
+            k = rnd.choice(list(live))
+            pl.release(*live.pop(k))
+        else:
+            off, n = pl.alloc(rnd.randint(1, 5000))
+            for o2, n2 in live.values():
+                assert off + n <= o2 or o2 + n2 <= off, "overlap"
+            live[step] = (off, n)
+    for v in live.values():
+        pl.release(*v)
+    assert pl.top == 0 and not pl.holes
+
+
+def test_schedule_and_coefficients_match_reference_tables(golden_blocks):
+    z = golden_blocks
+    for steps in (5, 10, 100):
+        tab = A.step_coefficients(steps, 0.0)
+        assert np.array_equal(tab[:, 0].numpy(), z[f"sched{steps}/t"])
+        assert np.array_equal(tab[:, 1].numpy(), z[f"sched{steps}/alpha"])
+        assert np.array_equal(tab[:, 2].numpy(), z[f"sched{steps}/sigma"])
+        assert np.array_equal(tab[:-1, 3].numpy(), z[f"sched{steps}/alpha"][1:])
+        assert np.array_equal(tab[:-1, 4].numpy(), z[f"sched{steps}/sigma"][1:])     # eta=0: adjusted == sigma_next
+        assert tab[-1, 6] == 1 and tab[:-1, 6].abs().sum() == 0
+    a, s = A.get_alphas_sigmas(torch.from_numpy(z["sched10/t"]))
+    assert np.array_equal(A.alpha_sigma_to_t(a, s).numpy(), z["sched10/t_back"])
+    with pytest.raises(RuntimeError):
+        A.sample(lambda x, t: x, torch.zeros(1, 2, 16), 2, 0)        # CPU tensors: no fallback
+
+
+def test_pqmf_design_matches_reference_tables(golden_pqmf):
+    z = golden_pqmf
+    for ch, att, M in ((2, 70, 4), (2, 70, 16), (2, 70, 32), (2, 100, 32)):
+        q = A.CachedPQMF(ch, att, M)
+        tag = f"pqmf_c{ch}_a{att}_m{M}"
+        sd = q.state_dict()
+        assert set(sd) == {"hk", "h", "forward_conv.weight", "inverse_conv.weight"}
+        for key, ref in (("hk", "hk"), ("h", "h"), ("forward_conv.weight", "fw"), ("inverse_conv.weight", "iw")):
+            assert sd[key].shape == tuple(z[f"{tag}/{ref}"].shape)
+            assert float((sd[key] - torch.from_numpy(z[f"{tag}/{ref}"])).abs().max()) <= 1e-6

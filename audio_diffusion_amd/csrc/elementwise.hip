@@ -6,6 +6,10 @@
 //   step_advance : ++*step, so one captured hipGraph replays every step of the loop
 #include "adk_common.h"
 
+// The DDIM update must round every product like the reference's separate ATen mul/add kernels do:
+// no fused multiply-add anywhere in this file (hipcc contracts by default).
+#pragma clang fp contract(off)
+
 struct PackArgs {
     const float* x; const float* t; const int32_t* step; const float* fw; void* y;
     int B, L, P, Lp, Cx, nplanes, t_stride; long long M;
@@ -21,7 +25,8 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const PackArgs a)
         const float tv = a.step ? a.t[(long long)(*a.step) * a.t_stride] : a.t[b];
         const int j = threadIdx.x & 7;
         // 2 * math.pi * input @ weight.T : ((2*pi) * t) * w, each product rounded to f32
-        const float f = __fmul_rn(__fmul_rn(6.283185307179586f, tv), a.fw[j]);
+        const float tp = 6.283185307179586f * tv;
+        const float f = tp * a.fw[j];
         emb[threadIdx.x] = threadIdx.x < 8 ? cosf(f) : sinf(f);
     }
     __syncthreads();
@@ -104,11 +109,16 @@ __global__ __launch_bounds__(256) void ddim_update_kernel(const DdimArgs a)
     const bool last = c[6] != 0.f;
     auto one = [&](float x, float v, float nz, float& pred) -> float {
         // literal order of sampling.py:34-35,48,52; no FMA contraction so CPU fp32 matches bitwise
-        pred = __fsub_rn(__fmul_rn(x, alpha), __fmul_rn(v, sigma));
-        const float eps = __fadd_rn(__fmul_rn(x, sigma), __fmul_rn(v, alpha));
+        // (plain operators: contraction is off in this file; the __f*_rn intrinsics would inline with
+        // the header's contract flag and fuse)
+        const float xa = x * alpha, vs = v * sigma;
+        pred = xa - vs;
+        const float xsg = x * sigma, va = v * alpha;
+        const float eps = xsg + va;
         if (last) return x;
-        float xn = __fadd_rn(__fmul_rn(pred, alpha_n), __fmul_rn(eps, adj));
-        if (NOISE) xn = __fadd_rn(xn, __fmul_rn(nz, dsig));
+        const float pa = pred * alpha_n, ea = eps * adj;
+        float xn = pa + ea;
+        if (NOISE) { const float nd = nz * dsig; xn = xn + nd; }
         return xn;
     };
     const long long stride = (long long)gridDim.x * 256;

@@ -81,6 +81,7 @@ class _Plan:
         self.planner = _ArenaPlanner()
         self.peak = 0
         self._ops = []            # (AdkOp, {field: ('arena', off) | ('abs', ptr)})
+        self.meta = []            # per-op bookkeeping for profiling (algorithmic FLOPs / bytes)
         self._keep = []           # device tensors that must outlive the plan (weights, tables)
         self.t_table = t_table
         self._build()
@@ -146,6 +147,7 @@ class _Plan:
         for k, v in fields.items():
             setattr(op, k, v)
         self._ops.append((op, ptrs))
+        self.meta.append({"kind": kind})
         return op
 
     def conv(self, x, key, w, bias, Cout, out=None, residual=None, stats=False, out_f32=False):
@@ -162,6 +164,8 @@ class _Plan:
             ptrs["residual"] = ("arena", residual.off)
         flags = _lib.FLAG_OUT_F32 if (out_f32 and self.dtype != torch.float32) else 0
         op = self._emit(_lib.OP_CONV, ptrs, flags=flags, L=x.L, Cin=cin_alloc, Cout=Cout, CoutPad=cout_pad, taps=taps)
+        self.meta[-1].update(taps=taps, L=x.L, cin=w.shape[1], cout=Cout, cotile=bn,
+                             flops=2.0 * w.shape[1] * Cout * taps * x.L * self.B)
         part = None
         if stats:
             n = self.lib.adk_partials_count(ctypes.byref(op))
@@ -180,6 +184,8 @@ class _Plan:
             ptrs["residual"] = ("arena", residual.off)
         op = self._emit(_lib.OP_GN_APPLY, ptrs, flags=_lib.FLAG_GELU if gelu else 0, L=x.L, Cin=x.C, Cout=x.C,
                         n_partials_in=part.C, f0=GN_EPS)
+        esz = 4 if x.f32 else 2
+        self.meta[-1].update(L=x.L, c=x.C, bytes=float(self.B) * x.C * x.L * esz * (3 if residual is not None else 2))
         pout = None
         if stats:
             cnt = self.lib.adk_partials_count(ctypes.byref(op))
@@ -194,6 +200,7 @@ class _Plan:
         ptrs = {"x": ("arena", x.off), "y": ("arena", y.off),
                 "w": ("abs", self._padded_vec(key, taps, taps.numel()))}
         self._emit(_lib.OP_FIR_UP if up else _lib.OP_FIR_DOWN, ptrs, L=x.L, Cin=x.C, taps=taps.numel())
+        self.meta[-1].update(L=x.L, c=x.C, bytes=float(self.B) * x.C * (x.L + Lo) * (4 if x.f32 else 2))
         return y
 
     # ---- module lowering -----------------------------------------------------------------

@@ -6,9 +6,9 @@
 //   B operand (MFMA cols)  = activation rows (CPL: one 64-byte row per position per channel chunk)
 // One K-stage = one channel chunk (64 B per row): the X tile (BM + taps - 1 rows) is staged ONCE in
 // LDS and re-read at `taps` row shifts; the zero padding of the convolution is read from the halo
-// rows of the layout.  LDS rows are padded 64 -> 80 B so every ds_read_b128 fragment read is
-// conflict-free.  Register-staged software pipeline: the next chunk's global loads are issued
-// before the current chunk's MFMAs.
+// rows of the layout.  Tiles reach LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging, no ds_write),
+// XOR-swizzled on the source address so every ds_read_b128 fragment read is conflict-free.  Two or three
+// blocks are co-resident per CU: one block's DMA overlaps another block's MFMAs.
 //   bf16: v_mfma_f32_32x32x16_bf16 (fp32 accumulate);  f32: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain).
 // Epilogue: + bias, (+ residual), per-tile (sum, sumsq) partials for the following GroupNorm(1,C)
 // (deterministic: fixed-order tree, no atomics), halo rows of the output zeroed by the edge tiles.
@@ -56,122 +56,12 @@ __device__ __forceinline__ void load4(const bf16_t* p, float (&v)[4]) {
     v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
 }
 
-constexpr int ROWB = 80;   // LDS row stride (64 B payload + 16 B pad)
-
-template <typename T, typename TO, int TAPS, int WCO, int WPOS, int TCO, int TPOS>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a)
+template <typename TO, int BN, int BM, int WPOS, int TCO, int TPOS>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TCO][TPOS], unsigned char* smem,
+                                              int b, int t, int cot, int cobase, int l0, int tid, int l31, int h,
+                                              int wco, int wpos)
 {
-    constexpr int BN = WCO * TCO * 32;           // output channels per block (MFMA rows)
-    constexpr int BM = WPOS * TPOS * 32;         // positions per block (MFMA cols)
-    constexpr int XROWS = BM + TAPS - 1;
-    constexpr int XPIECES = XROWS * 4, WPIECES = TAPS * BN * 4;
-    constexpr int NX = (XPIECES + 255) / 256, NW = (WPIECES + 255) / 256;
     constexpr int CBO = ElemTraits<TO>::CB;
-    static_assert(WCO * WPOS == 4, "4 waves per block");
-    typedef typename Mma<T>::Frag Frag;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* xs = smem;
-    unsigned char* ws = smem + XROWS * ROWB;
-
-    const unsigned lid = xcd_remap(blockIdx.x, a.nblk);
-    const int cot = (int)(lid % (unsigned)a.ncot);
-    const unsigned r1 = lid / (unsigned)a.ncot;
-    const int t = (int)(r1 % (unsigned)a.tps);
-    const int b = (int)(r1 / (unsigned)a.tps);
-    const int cobase = cot * BN;
-    const int l0 = t * BM;
-    const long long mrow0 = (long long)b * a.Lp + a.P + l0 - TAPS / 2;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
-    const int wco = wave / WPOS, wpos = wave % WPOS;
-
-    // ---- per-thread staging geometry (32-bit offsets from per-chunk base pointers) ----
-    unsigned xoff[NX], woff[NW];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        const int p = tid + 256 * i, row = p >> 2, q = p & 3;
-        long long m = mrow0 + row;
-        m = m < 0 ? 0 : (m >= a.M ? a.M - 1 : m);
-        xoff[i] = (unsigned)(m * 64 + q * 16);
-    }
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        const int p = tid + 256 * i, r = p >> 2, q = p & 3;
-        const int tap = r / BN, col = r % BN;
-        woff[i] = (unsigned)(((tap * a.CoutPad) + cobase + col) * 64 + q * 16);
-    }
-    const unsigned char* xg = reinterpret_cast<const unsigned char*>(a.x);
-    const unsigned char* wg = reinterpret_cast<const unsigned char*>(a.w);
-    const long long xplane = a.M * 64;
-    const long long wchunk = (long long)TAPS * a.CoutPad * 64;
-
-    uint4 xr[NX], wr[NW];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) xr[i] = make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < NW; ++i) wr[i] = make_uint4(0, 0, 0, 0);
-#define LOAD_STAGE(kc_)                                                                             \
-    {                                                                                               \
-        const unsigned char* xb_ = xg + (kc_) * xplane;                                             \
-        const unsigned char* wb_ = wg + (kc_) * wchunk;                                             \
-        _Pragma("unroll") for (int i = 0; i < NX; ++i)                                              \
-            if (XPIECES % 256 == 0 || i + 1 < NX || tid + 256 * i < XPIECES)                        \
-                xr[i] = *reinterpret_cast<const uint4*>(xb_ + xoff[i]);                             \
-        _Pragma("unroll") for (int i = 0; i < NW; ++i)                                              \
-            if (WPIECES % 256 == 0 || i + 1 < NW || tid + 256 * i < WPIECES)                        \
-                wr[i] = *reinterpret_cast<const uint4*>(wb_ + woff[i]);                             \
-    }
-#define STORE_STAGE()                                                                               \
-    {                                                                                               \
-        _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                            \
-            const int p_ = tid + 256 * i;                                                           \
-            if (XPIECES % 256 == 0 || i + 1 < NX || p_ < XPIECES)                                   \
-                *reinterpret_cast<uint4*>(xs + (p_ >> 2) * ROWB + (p_ & 3) * 16) = xr[i];           \
-        }                                                                                           \
-        _Pragma("unroll") for (int i = 0; i < NW; ++i) {                                            \
-            const int p_ = tid + 256 * i;                                                           \
-            if (WPIECES % 256 == 0 || i + 1 < NW || p_ < WPIECES)                                   \
-                *reinterpret_cast<uint4*>(ws + (p_ >> 2) * ROWB + (p_ & 3) * 16) = wr[i];           \
-        }                                                                                           \
-    }
-
-    f32x16 acc[TCO][TPOS];
-#pragma unroll
-    for (int i = 0; i < TCO; ++i)
-#pragma unroll
-        for (int j = 0; j < TPOS; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const unsigned char* wfrag = ws + (wco * TCO * 32 + l31) * ROWB + 16 * h;
-    const unsigned char* xfrag = xs + (wpos * TPOS * 32 + l31) * ROWB + 16 * h;
-
-    LOAD_STAGE(0);
-    for (int kc = 0; kc < a.nchunks; ++kc) {
-        __syncthreads();                 // previous chunk's fragment reads are done
-        STORE_STAGE();
-        __syncthreads();
-        if (kc + 1 < a.nchunks) LOAD_STAGE(kc + 1);   // in flight under the MFMAs below
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                Frag af[TCO], bf[TPOS];
-#pragma unroll
-                for (int i = 0; i < TCO; ++i)
-                    af[i] = *reinterpret_cast<const Frag*>(wfrag + (tap * BN + i * 32) * ROWB + 32 * s);
-#pragma unroll
-                for (int j = 0; j < TPOS; ++j)
-                    bf[j] = *reinterpret_cast<const Frag*>(xfrag + (j * 32 + tap) * ROWB + 32 * s);
-#pragma unroll
-                for (int i = 0; i < TCO; ++i)
-#pragma unroll
-                    for (int j = 0; j < TPOS; ++j) Mma<T>::run(af[i], bf[j], acc[i][j]);
-            }
-        }
-    }
-
     // ---- epilogue: lane (l31, h) holds D[co = 8g + 4h + e][pos = l31] in acc[..][4g + e] ----
     TO* yg = reinterpret_cast<TO*>(a.y);
     const TO* rg = reinterpret_cast<const TO*>(a.residual);
@@ -236,6 +126,250 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a)
     }
 }
 
+// LDS image: plain 64-byte rows filled by LDS-DMA (global_load_lds_dwordx4: 1 KiB = 16 rows per wave
+// instruction, destination lane-linear), XOR-swizzled through the SOURCE address: the 16-byte piece p of
+// row r is stored in slot p ^ ((r >> 2) & 3), which makes every ds_read_b128 fragment read conflict-free
+// (a 16-lane read group then touches 16 distinct 16-byte slots of the 256-byte bank row).
+__device__ __forceinline__ void glds16(const unsigned char* src, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T, typename TO, int TAPS, int WCO, int WPOS, int TCO, int TPOS>
+__global__ __launch_bounds__(256, 2) void conv_mfma_simple_kernel(const ConvArgs a)
+{
+    constexpr int BN = WCO * TCO * 32;           // output channels per block (MFMA rows)
+    constexpr int BM = WPOS * TPOS * 32;         // positions per block (MFMA cols)
+    constexpr int XROWS = BM + TAPS - 1;
+    constexpr int NXI = (XROWS + 15) / 16;       // 1-KiB LDS-DMA instructions for the X tile
+    constexpr int NWI = TAPS * BN / 16;          // ... for the W tile
+    static_assert(WCO * WPOS == 4, "4 waves per block");
+    static_assert(BN % 32 == 0, "co tile");
+    typedef typename Mma<T>::Frag Frag;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* xs = smem;
+    unsigned char* ws = smem + NXI * 1024;
+
+    const unsigned lid = xcd_remap(blockIdx.x, a.nblk);
+    const int cot = (int)(lid % (unsigned)a.ncot);
+    const unsigned r1 = lid / (unsigned)a.ncot;
+    const int t = (int)(r1 % (unsigned)a.tps);
+    const int b = (int)(r1 / (unsigned)a.tps);
+    const int cobase = cot * BN;
+    const int l0 = t * BM;
+    const long long mrow0 = (long long)b * a.Lp + a.P + l0 - TAPS / 2;
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave / WPOS, wpos = wave % WPOS;
+
+    // ---- LDS-DMA source addressing: this lane fills slot (lane & 3) of row 16*j + (lane >> 2) ----
+    const int srow = lane >> 2, sslot = lane & 3;
+    const unsigned char* xg = reinterpret_cast<const unsigned char*>(a.x);
+    const unsigned char* wg = reinterpret_cast<const unsigned char*>(a.w);
+    const long long xplane = a.M * 64;
+    const long long wchunk = (long long)TAPS * a.CoutPad * 64;
+
+    auto stage = [&](int kc) {
+        const unsigned char* xb = xg + kc * xplane;
+        const unsigned char* wb = wg + kc * wchunk;
+#pragma unroll
+        for (int j0 = 0; j0 < NXI; j0 += 4) {
+            const int j = j0 + wave;
+            if (j < NXI) {
+                const int row = j * 16 + srow;
+                long long m = mrow0 + row;
+                m = m < 0 ? 0 : (m >= a.M ? a.M - 1 : m);
+                glds16(xb + m * 64 + ((sslot ^ ((row >> 2) & 3)) << 4), xs + j * 1024);
+            }
+        }
+#pragma unroll
+        for (int j0 = 0; j0 < NWI; j0 += 4) {
+            const int j = j0 + wave;
+            if (j < NWI) {
+                const int row = j * 16 + srow;              // = tap * BN + co_local
+                const int tap = row / BN, col = row % BN;
+                glds16(wb + (long long)(tap * a.CoutPad + cobase + col) * 64 + ((sslot ^ ((row >> 2) & 3)) << 4),
+                       ws + j * 1024);
+            }
+        }
+    };
+
+    f32x16 acc[TCO][TPOS];
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int j = 0; j < TPOS; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment rows: weights at (tap*BN + wco*TCO*32 + i*32 + l31), activations at (wpos*TPOS*32 + j*32 + l31 + tap)
+    const unsigned char* wfrag = ws + (wco * TCO * 32 + l31) * 64;
+    const unsigned char* xfrag = xs + (wpos * TPOS * 32 + l31) * 64;
+    const int wsw = (l31 >> 2) & 3;              // tile offsets are multiples of 16 rows: swizzle depends on l31 only
+
+    for (int kc = 0; kc < a.nchunks; ++kc) {
+        stage(kc);
+        __syncthreads();                         // waits for this wave's LDS-DMA (vmcnt) + block barrier
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int xsw = ((l31 + tap) >> 2) & 3;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int p = 2 * s + h;
+                Frag af[TCO], bf[TPOS];
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
+                    af[i] = *reinterpret_cast<const Frag*>(wfrag + (tap * BN + i * 32) * 64 + ((p ^ wsw) << 4));
+#pragma unroll
+                for (int j = 0; j < TPOS; ++j)
+                    bf[j] = *reinterpret_cast<const Frag*>(xfrag + (j * 32 + tap) * 64 + ((p ^ xsw) << 4));
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                    for (int j = 0; j < TPOS; ++j) Mma<T>::run(af[i], bf[j], acc[i][j]);
+            }
+        }
+        __syncthreads();                         // every wave is done reading before the next stage lands
+    }
+
+    conv_epilogue<TO, BN, BM, WPOS, TCO, TPOS>(a, acc, smem, b, t, cot, cobase, l0, tid, l31, h, wco, wpos);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pipelined variant (co tile 128): the K loop runs in PHASES of one (channel chunk, tap) each.  The
+// unit of prefetch is one tap's weight tile W(kc, tap) (128 rows x 64 B = 8 KiB = 2 LDS-DMA instructions
+// per wave) held in a ring of D+1 slots; the activation tile X(kc) (BM + taps - 1 rows, shared by all
+// taps of the chunk) is double-buffered and issued just ahead of W(kc, 0).  Every wave issues the same
+// number of LDS-DMA instructions per unit, so "unit g has landed" is one counted s_waitcnt vmcnt(N)
+// (N = this wave's instructions issued AFTER unit g, a compile-time constant per tap) followed by one
+// raw s_barrier per phase; D units stay in flight across barriers (never vmcnt(0) in steady state).
+//   phase g:  wait unit g (counted) -> s_barrier -> issue unit g+D (into the slot phase g-1 just
+//             released) -> ds_read fragments + MFMAs of (kc, tap).
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, typename TO, int TAPS, int WCO, int WPOS, int TCO, int TPOS>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a)
+{
+    constexpr int BN = WCO * TCO * 32, BM = WPOS * TPOS * 32;
+    static_assert(WCO * WPOS == 4 && BN == 128, "pipelined variant: 4 waves, 128-channel co tile");
+    constexpr int D = TAPS >= 3 ? 3 : 1;         // weight units in flight ahead of the consumer
+    // one slot more than the minimum: the slot refilled after phase g's barrier was last read in phase g-2,
+    // so a fragment read the compiler issued just ahead of a barrier can never race the refill
+    constexpr int RW = D + 2, RX = TAPS == 1 ? 3 : 2;
+    constexpr int XROWS = BM + TAPS - 1;
+    constexpr int XI = (XROWS + 63) / 64;        // X LDS-DMA instructions per wave (uniform; tile padded)
+    constexpr int WI = BN / 64;                  // W LDS-DMA instructions per wave per unit
+    constexpr int XBYTES = XI * 4096, WBYTES = BN * 64;
+    typedef typename Mma<T>::Frag Frag;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* xs = smem;                    // [RX][XBYTES]
+    unsigned char* ws = smem + RX * XBYTES;      // [RW][WBYTES]
+
+    const unsigned lid = xcd_remap(blockIdx.x, a.nblk);
+    const int cot = (int)(lid % (unsigned)a.ncot);
+    const unsigned r1 = lid / (unsigned)a.ncot;
+    const int t = (int)(r1 % (unsigned)a.tps);
+    const int b = (int)(r1 / (unsigned)a.tps);
+    const int cobase = cot * BN;
+    const int l0 = t * BM;
+    const long long mrow0 = (long long)b * a.Lp + a.P + l0 - TAPS / 2;
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave / WPOS, wpos = wave % WPOS;
+    const int srow = lane >> 2, sslot = lane & 3;
+
+    const unsigned char* xg = reinterpret_cast<const unsigned char*>(a.x);
+    const unsigned char* wg = reinterpret_cast<const unsigned char*>(a.w);
+    const long long xplane = a.M * 64;
+    const long long wchunk = (long long)TAPS * a.CoutPad * 64;
+    const int total = a.nchunks * TAPS;
+
+    // per-lane source offsets (bytes) inside a plane / a weight chunk, fixed for the whole kernel
+    unsigned xsrc[XI], wsrc[WI];
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+        const int row = (j * 4 + wave) * 16 + srow;
+        long long m = mrow0 + row;
+        m = m < 0 ? 0 : (m >= a.M ? a.M - 1 : m);
+        xsrc[j] = (unsigned)(m * 64 + ((sslot ^ ((row >> 2) & 3)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < WI; ++j) {
+        const int row = (j * 4 + wave) * 16 + srow;          // co_local
+        wsrc[j] = (unsigned)((cobase + row) * 64 + ((sslot ^ ((row >> 2) & 3)) << 4));
+    }
+
+    auto issue_unit = [&](int u) {               // u = kc * TAPS + tap, wave-uniform
+        const int kc = u / TAPS, tap = u - kc * TAPS;
+        if (tap == 0) {
+            const unsigned char* xb = xg + kc * xplane;
+            unsigned char* dst = xs + (kc % RX) * XBYTES + wave * 1024;
+#pragma unroll
+            for (int j = 0; j < XI; ++j) glds16(xb + xsrc[j], dst + j * 4096);
+        }
+        const unsigned char* wb = wg + kc * wchunk + (long long)tap * a.CoutPad * 64;
+        unsigned char* dst = ws + (u % RW) * WBYTES + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < WI; ++j) glds16(wb + wsrc[j], dst + j * 4096);
+    };
+
+    f32x16 acc[TCO][TPOS];
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int j = 0; j < TPOS; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wfrag = (wco * TCO * 32 + l31) * 64;
+    const int xfrag = (wpos * TPOS * 32 + l31) * 64;
+    const int wsw = (l31 >> 2) & 3;
+
+#pragma unroll
+    for (int u = 0; u < D; ++u)
+        if (u < total) issue_unit(u);
+
+// instructions this wave issued after unit (kc, TAP_) when phase (kc, TAP_) starts: units +1 .. +D-1
+#define ADK_PHASE(TAP_)                                                                                      \
+    if constexpr (TAP_ < TAPS) {                                                                             \
+        constexpr int n_mid = []() { int n = 0; for (int u = 1; u < D; ++u) n += WI + ((TAP_ + u) % TAPS == 0 ? XI : 0); return n; }(); \
+        constexpr int n_last = []() { int n = 0; for (int u = 1; u < D; ++u) n += (TAP_ + u < TAPS) ? WI : 0; return n; }();          \
+        if (last) wait_vmcnt<n_last>(); else wait_vmcnt<n_mid>();                                            \
+        __builtin_amdgcn_s_barrier();                                                                        \
+        asm volatile("" ::: "memory");                                                                       \
+        const int g_ = kc * TAPS + TAP_;                                                                     \
+        if (g_ + D < total) issue_unit(g_ + D);                                                              \
+        const unsigned char* wt_ = ws + (g_ % RW) * WBYTES + wfrag;                                          \
+        const unsigned char* xt_ = xs + (kc % RX) * XBYTES + xfrag + TAP_ * 64;                              \
+        const int xsw_ = ((l31 + TAP_) >> 2) & 3;                                                            \
+        _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                   \
+            const int p_ = 2 * s_ + h;                                                                       \
+            Frag af_[TCO], bf_[TPOS];                                                                        \
+            _Pragma("unroll") for (int i = 0; i < TCO; ++i)                                                  \
+                af_[i] = *reinterpret_cast<const Frag*>(wt_ + i * 2048 + ((p_ ^ wsw) << 4));                 \
+            _Pragma("unroll") for (int j = 0; j < TPOS; ++j)                                                 \
+                bf_[j] = *reinterpret_cast<const Frag*>(xt_ + j * 2048 + ((p_ ^ xsw_) << 4));                \
+            _Pragma("unroll") for (int i = 0; i < TCO; ++i)                                                  \
+                _Pragma("unroll") for (int j = 0; j < TPOS; ++j) Mma<T>::run(af_[i], bf_[j], acc[i][j]);     \
+        }                                                                                                    \
+    }
+
+    for (int kc = 0; kc < a.nchunks; ++kc) {
+        const bool last = kc == a.nchunks - 1;
+        ADK_PHASE(0) ADK_PHASE(1) ADK_PHASE(2) ADK_PHASE(3) ADK_PHASE(4)
+    }
+#undef ADK_PHASE
+    __syncthreads();      // all fragment reads done before the epilogue reuses LDS for its reduction
+
+    conv_epilogue<TO, BN, BM, WPOS, TCO, TPOS>(a, acc, smem, b, t, cot, cobase, l0, tid, l31, h, wco, wpos);
+}
+
 // ------------------------------------------------------------------------------------------------
 template <typename T, typename TO, int TAPS, int WCO, int WPOS, int TCO, int TPOS>
 static int launch_variant(const adk_op& op, hipStream_t st)
@@ -251,25 +385,44 @@ static int launch_variant(const adk_op& op, hipStream_t st)
     a.tps = (op.L + BM - 1) / BM;
     a.ncot = op.CoutPad / BN;
     a.nblk = (unsigned)(op.B * a.tps * a.ncot);
-    const size_t lds = (size_t)(BM + TAPS - 1) * ROWB + (size_t)TAPS * BN * ROWB;
-    hipLaunchKernelGGL((conv_mfma_kernel<T, TO, TAPS, WCO, WPOS, TCO, TPOS>), dim3(a.nblk), dim3(256), lds, st, a);
+    if constexpr (BN == 128) {
+        constexpr int D = TAPS >= 3 ? 3 : 1;
+        constexpr int XI = (BM + TAPS - 1 + 63) / 64;
+        const size_t lds = (size_t)(TAPS == 1 ? 3 : 2) * XI * 4096 + (size_t)(D + 2) * BN * 64;
+        hipLaunchKernelGGL((conv_mfma_kernel<T, TO, TAPS, WCO, WPOS, TCO, TPOS>), dim3(a.nblk), dim3(256), lds, st, a);
+    } else {
+        const size_t lds = (size_t)((BM + TAPS - 1 + 15) / 16) * 1024 + (size_t)TAPS * BN * 64;
+        hipLaunchKernelGGL((conv_mfma_simple_kernel<T, TO, TAPS, WCO, WPOS, TCO, TPOS>), dim3(a.nblk), dim3(256), lds, st, a);
+    }
     return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
 }
 
-// tile-shape selection; must agree with adk_conv_cotile / conv_partials_count
+// tile-shape selection (host); adk_conv_cotile / adk_conv_postile / adk_partials_count report it
 static inline int conv_bn(int Cout) { return Cout <= 32 ? 32 : 128; }
-static inline int conv_bm(int Cout, int L) { return (Cout <= 32 || L > 64) ? 128 : (L > 32 ? 64 : 32); }
+static inline int conv_bm(const adk_op& op)
+{
+    if (conv_bn(op.Cout) == 32) return 128;
+    if (op.L <= 32) return 32;
+    if (op.L <= 64) return 64;
+    // wide tile (W amortised over 256 positions) only while it still leaves >= 2 blocks per CU
+    const long long wide = (long long)op.B * ((op.L + 255) / 256) * (op.CoutPad / 128);
+    return (op.L >= 256 && wide >= 512) ? 256 : 128;
+}
 
 int conv_cotile(int Cout) { return conv_bn(Cout); }
-int conv_partials_count(int Cout, int CoutPad, int L) {
-    return ((L + conv_bm(Cout, L) - 1) / conv_bm(Cout, L)) * (CoutPad / conv_bn(Cout));
+int conv_postile(const adk_op& op) { return conv_bm(op); }
+int conv_partials_count(const adk_op& op)
+{
+    const int bm = conv_bm(op);
+    return ((op.L + bm - 1) / bm) * (op.CoutPad / conv_bn(op.Cout));
 }
 
 template <typename T, typename TO, int TAPS>
 static int launch_tiles(const adk_op& op, hipStream_t st)
 {
-    const int bn = conv_bn(op.Cout), bm = conv_bm(op.Cout, op.L);
+    const int bn = conv_bn(op.Cout), bm = conv_bm(op);
     if (bn == 32) return launch_variant<T, TO, TAPS, 1, 4, 1, 1>(op, st);
+    if (bm == 256) return launch_variant<T, TO, TAPS, 2, 2, 2, 4>(op, st);
     if (bm == 128) return launch_variant<T, TO, TAPS, 2, 2, 2, 2>(op, st);
     if (bm == 64) return launch_variant<T, TO, TAPS, 2, 2, 2, 1>(op, st);
     return launch_variant<T, TO, TAPS, 4, 1, 1, 1>(op, st);

@@ -65,13 +65,16 @@ def conv_roofline(model, B, dtype, dev, reps=3):
     out = torch.empty_like(x)
     plan.bind(x.data_ptr(), tt.data_ptr(), out.data_ptr())
     stream = torch.cuda.current_stream(dev)
-    idx = [i for i, m in enumerate(plan.meta) if m["kind"] == _lib.OP_CONV and m["taps"] == 5 and m["cotile"] == 128]
-    total_ms, launches = 0.0, 0
-    flops = sum(plan.meta[i]["flops"] for i in idx)
+    groups = {}
+    for i, m in enumerate(plan.meta):
+        if m["kind"] == _lib.OP_CONV and m["taps"] == 5 and m["cotile"] == 128:
+            groups.setdefault(m["postile"], []).append(i)
+    timed = set(i for g in groups.values() for i in g)
+    ms = {i: 0.0 for i in timed}
     for r in range(reps + 1):
         evs = {}
         for i in range(plan.n_ops):
-            if i in idx:
+            if i in timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
                 _lib.run_ops(_offset(plan.ops, i), 1, stream.cuda_stream)
@@ -81,15 +84,24 @@ def conv_roofline(model, B, dtype, dev, reps=3):
                 _lib.run_ops(_offset(plan.ops, i), 1, stream.cuda_stream)
         torch.cuda.synchronize(dev)
         if r:                                        # first pass is a warm-up
-            total_ms += sum(e0.elapsed_time(e1) for e0, e1 in evs.values())
-            launches += len(evs)
-    per_call_ms = total_ms / reps
+            for i, (e0, e1) in evs.items():
+                ms[i] += e0.elapsed_time(e1) / reps
     key = "bf16" if dtype == torch.bfloat16 else "fp32"
-    achieved = flops / (per_call_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "conv_mfma_kernel<k=5, 128co x 128pos tile>", "achieved": achieved,
-            "peak": PEAK[key], "unit": "TFLOP/s", "frac": achieved / PEAK[key], "traffic": None,
-            "launches_per_call": len(idx), "avg_launch_us": 1e3 * total_ms / max(launches, 1),
-            "flop_per_call": flops, "share_of_call_flop": flops / (6.899e11 * B)}
+    per = {}
+    for pt, idx in groups.items():
+        fl = sum(plan.meta[i]["flops"] for i in idx)
+        tm = sum(ms[i] for i in idx)
+        per[pt] = {"launches_per_call": len(idx), "avg_launch_us": 1e3 * tm / len(idx), "flop_per_call": fl,
+                   "tflops": fl / (tm * 1e-3) / 1e12, "ms_per_call": tm}
+    dom = max(per, key=lambda k: per[k]["flop_per_call"])
+    d = per[dom]
+    return {"bound": "mfma", "kernel": f"conv_mfma_kernel<{key}, taps=5, tile 128co x {dom}pos>",
+            "achieved": d["tflops"], "peak": PEAK[key], "unit": "TFLOP/s", "frac": d["tflops"] / PEAK[key],
+            "traffic": None, "launches_per_call": d["launches_per_call"], "avg_launch_us": d["avg_launch_us"],
+            "flop_per_launch_avg": d["flop_per_call"] / d["launches_per_call"],
+            "share_of_call_flop": d["flop_per_call"] / (6.899e11 * B),
+            "other_tiles": {str(k): {"tflops": v["tflops"], "launches_per_call": v["launches_per_call"],
+                                     "avg_launch_us": v["avg_launch_us"]} for k, v in per.items() if k != dom}}
 
 
 def _offset(ops, i):

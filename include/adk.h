@@ -88,6 +88,9 @@ int adk_validate_plan(const adk_op *ops, int n);
 /* Number of (sum,sumsq) pairs per sample that an op writes to partials_out (0 if none). */
 int adk_partials_count(const adk_op *op);
 
+/* Positions per block (32, 64, 128 or 256) the conv kernel will use for this op (needs B, L, Cout, CoutPad). */
+int adk_conv_postile(const adk_op *op);
+
 /* Co-tile (rows of packed weight must be a multiple of this) the conv kernel will use. */
 int adk_conv_cotile(int dtype, int Cout, int L);
 

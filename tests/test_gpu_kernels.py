@@ -51,6 +51,8 @@ CONV_CASES = [
     (2, 24, 96, 64, 1, False, True),       # 1x1, no bias, residual
     (2, 384, 256, 2, 5, True, False),      # narrow-output variant (co tile 32)
     (1, 1024, 32, 32, 1, True, False),
+    (8, 16384, 32, 128, 5, True, False),   # wide (256-position) tile variant
+    (9, 16500, 64, 256, 5, True, True),    # wide tile, ragged last tile, 2 co tiles
 ]
 
 
@@ -84,7 +86,7 @@ def test_conv1d(env, dt, case):
     planes_out = (Cout + cb - 1) // cb
     yd = torch.full((planes_out, B, L + 2 * P, cb), 7.0, dtype=dtype, device=dev)   # poison incl. halo
     op = _lib.AdkOp()
-    op.kind, op.dtype, op.L, op.Cout, op.CoutPad, op.Cin = _lib.OP_CONV, adk, L, Cout, cout_pad, cin_alloc
+    op.kind, op.dtype, op.L, op.Cout, op.CoutPad, op.Cin, op.B = _lib.OP_CONV, adk, L, Cout, cout_pad, cin_alloc, B
     npart = lib.adk_partials_count(C.byref(op))
     part = torch.zeros(B, npart, 2, device=dev)
     rc = lib.adk_conv1d(adk, 0, B, L, P, cin_alloc, Cout, cout_pad, taps, xd.data_ptr(), wd.data_ptr(),

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Per-op HIP-event timing of one denoiser call (eager, op by op), aggregated by kind / level.
+usage: python tools/profile_ops.py [--dtype bf16|fp32] [--batch 16] [--reps 3]"""
+import argparse
+import ctypes
+import os
+import sys
+from collections import defaultdict
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import audio_diffusion_amd as A
+from audio_diffusion_amd import _lib
+
+NAMES = {1: "conv", 2: "gn_apply", 3: "gn_stats", 4: "fir_down", 5: "fir_up", 6: "attn", 7: "pack", 8: "unpack",
+         9: "pqmf_a", 10: "pqmf_s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--T", type=int, default=65536)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)
+    m = A.DiffusionAttnUnet1D(n_attn_layers=4).to(dev).eval()
+    plan = m.plan_for(a.batch, a.T, dtype, dev)
+    x = torch.randn(a.batch, 2, a.T, device=dev)
+    t = torch.ones(a.batch, device=dev)
+    out = torch.empty_like(x)
+    plan.bind(x.data_ptr(), t.data_ptr(), out.data_ptr())
+    st = torch.cuda.current_stream(dev)
+    sz = ctypes.sizeof(_lib.AdkOp)
+    ms = [0.0] * plan.n_ops
+    for r in range(a.reps + 1):
+        evs = []
+        for i in range(plan.n_ops):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            _lib.run_ops(ctypes.cast(ctypes.byref(plan.ops, i * sz), ctypes.POINTER(_lib.AdkOp)), 1, st.cuda_stream)
+            e1.record(st)
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        if r:
+            for i, (e0, e1) in enumerate(evs):
+                ms[i] += e0.elapsed_time(e1) / a.reps
+    agg = defaultdict(lambda: [0, 0.0, 0.0, 0.0])
+    for i, meta in enumerate(plan.meta):
+        k = NAMES.get(meta["kind"], str(meta["kind"]))
+        if meta["kind"] == 1:
+            key = (k, f"k{meta['taps']}", f"L{meta['L']}", f"{meta['cin']}->{meta['cout']}", f"tile{meta['cotile']}x{meta['postile']}")
+        else:
+            key = (k, f"L{meta.get('L', 0)}", f"C{meta.get('c', 0)}")
+        e = agg[key]
+        e[0] += 1; e[1] += ms[i]; e[2] += meta.get("flops", 0.0); e[3] += meta.get("bytes", 0.0)
+    total = sum(ms)
+    print(f"total {total:.3f} ms over {plan.n_ops} ops (event-timed, includes launch gaps)")
+    bykind = defaultdict(float)
+    for key, e in agg.items():
+        bykind[key[0] + (key[1] if key[0] == "conv" else "")] += e[1]
+    for k, v in sorted(bykind.items(), key=lambda kv: -kv[1]):
+        print(f"  {k:12s} {v:8.3f} ms  {100 * v / total:5.1f}%")
+    print("-- detail (sorted by time)")
+    for key, e in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
+        rate = f"{e[2] / e[1] / 1e9:8.1f} TF/s" if e[2] else (f"{e[3] / e[1] / 1e9:8.2f} TB/s" if e[3] else "")
+        print(f"  {' '.join(key):55s} n={e[0]:3d} {e[1]:8.3f} ms  avg {1e3 * e[1] / e[0]:8.1f} us  {rate}")
+
+
+if __name__ == "__main__":
+    main()

@@ -36,7 +36,7 @@ class AdkOp(C.Structure):
 
 
 EXPORTS = [
-    "adk_version", "adk_last_error", "adk_run_plan", "adk_validate_plan", "adk_partials_count", "adk_conv_postile", "adk_conv_cotile",
+    "adk_version", "adk_last_error", "adk_run_plan", "adk_validate_plan", "adk_partials_count", "adk_conv_postile", "adk_conv_cotile_used", "adk_conv_cotile",
     "adk_conv1d", "adk_gn_apply", "adk_gn_stats", "adk_fir_down2", "adk_fir_up2", "adk_attn1d",
     "adk_pack_input", "adk_unpack_output", "adk_pqmf_analysis", "adk_pqmf_synthesis",
     "adk_ddim_update", "adk_step_advance",
@@ -68,6 +68,7 @@ def load():
     lib.adk_validate_plan.argtypes = [C.POINTER(AdkOp), i32]
     lib.adk_partials_count.argtypes = [C.POINTER(AdkOp)]
     lib.adk_conv_postile.argtypes = [C.POINTER(AdkOp)]
+    lib.adk_conv_cotile_used.argtypes = [C.POINTER(AdkOp)]
     lib.adk_conv_cotile.argtypes = [i32, i32, i32]
     lib.adk_conv1d.argtypes = [i32, u32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.adk_gn_apply.argtypes = [i32, u32, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp, vp, vp, vp, vp]

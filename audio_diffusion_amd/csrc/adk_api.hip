@@ -9,6 +9,7 @@ int launch_conv(const adk_op& op, hipStream_t st);
 int conv_cotile(int Cout);
 int conv_partials_count(const adk_op& op);
 int conv_postile(const adk_op& op);
+int conv_cotile_used(const adk_op& op);
 int launch_gn(const adk_op& op, hipStream_t st, bool apply);
 int gn_partials_count(int dtype, int C, int L);
 int launch_fir(const adk_op& op, hipStream_t st, bool up);
@@ -188,6 +189,8 @@ int adk_partials_count(const adk_op* op)
     if (op->kind == ADK_OP_GN_APPLY || op->kind == ADK_OP_GN_STATS) return gn_partials_count(op->dtype, op->Cin, op->L);
     return 0;
 }
+
+int adk_conv_cotile_used(const adk_op* op) { return (op && op->kind == ADK_OP_CONV) ? conv_cotile_used(*op) : 0; }
 
 int adk_conv_postile(const adk_op* op) { return (op && op->kind == ADK_OP_CONV) ? conv_postile(*op) : 0; }
 

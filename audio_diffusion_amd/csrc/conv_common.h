@@ -1,0 +1,52 @@
+// Shared pieces of the implicit-GEMM convolution kernels (conv_mfma.hip, conv_ksplit.hip).
+#pragma once
+#include "adk_common.h"
+
+struct ConvArgs {
+    const void* x; const void* w; const float* bias; const void* residual; void* y; float* partials;
+    int B, L, P, Lp;
+    long long M;
+    int nchunks, Cout_alloc, CoutPad, tps, ncot;
+    unsigned nblk;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    typedef bf16x8 Frag;
+    static __device__ __forceinline__ void run(const Frag& a, const Frag& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    typedef f32x4 Frag;
+    static __device__ __forceinline__ void run(const Frag& a, const Frag& b, f32x16& c) {
+        // lane (r, h) holds k = 4h + {0,1,2,3} of this 8-wide k group for both operands
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+}
+__device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void load4(const bf16_t* p, float (&v)[4]) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+
+
+// tile shape chosen on the host for one conv op (conv_mfma.hip: conv_tile)
+struct ConvTile { int bn, bm; bool ksplit; };
+ConvTile conv_tile(const adk_op& op);
+void conv_fill_args(const adk_op& op, int BN, int BM, ConvArgs& a);
+int launch_conv_ksplit(const adk_op& op, hipStream_t st);

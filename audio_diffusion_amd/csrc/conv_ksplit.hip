@@ -1,0 +1,204 @@
+// Implicit-GEMM Conv1d for SHORT levels (L <= 256): small (co, pos) tiles, K range split over the 4 waves.
+//
+// At L <= 256 the pipelined kernel of conv_mfma.hip has too few 128-row tiles to fill 256 CUs and runs a
+// serial K loop of up to 400 barrier-separated phases per block (21-28 us for < 1 % of the FLOPs).  Here a
+// block owns a (TCO*32 co) x (TPOS*32 pos) tile of ONE sample and its four waves each take every fourth
+// channel chunk: no barrier and no LDS in the K loop.  Both MFMA operands go straight from global memory
+// to VGPRs in fragment layout (one 16-byte piece per lane: 32 rows x 64 B = 2 KiB contiguous per
+// instruction; the weights are read once per block, the activation rows are L1/L2 hits re-read per tap),
+// register double-buffered one chunk (or four 1x1 units) ahead.  The four partial accumulators meet in LDS
+// and are summed in FIXED wave order (bit-reproducible); wave w finishes channel group 8w..8w+3 (+4h) of
+// every 32-channel sub-tile: + bias, + residual, GroupNorm partials, halo rows, store.
+// Same packed weights, same CPL activations, same epilogue semantics as conv_mfma.hip.
+#include "conv_common.h"
+
+template <typename T, typename TO, int TAPS, int TCO, int TPOS, int DEPTH>
+__global__ __launch_bounds__(256, (TCO * TPOS >= 4 ? 1 : 2)) void conv_ksplit_kernel(const ConvArgs a)
+{
+    constexpr int BN = TCO * 32, BM = TPOS * 32, S = TCO * TPOS;
+    constexpr int CBO = ElemTraits<TO>::CB;
+    typedef typename Mma<T>::Frag Frag;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const unsigned lid = xcd_remap(blockIdx.x, a.nblk);
+    const int cot = (int)(lid % (unsigned)a.ncot);
+    const unsigned r1 = lid / (unsigned)a.ncot;
+    const int t = (int)(r1 % (unsigned)a.tps);
+    const int b = (int)(r1 / (unsigned)a.tps);
+    const int cobase = cot * BN;
+    const int l0 = t * BM;
+    const int mrow0 = b * a.Lp + a.P + l0 - TAPS / 2;          // >= 0: P >= TAPS/2 (validated on the host)
+    const int mlast = (int)a.M - 1;
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nck = a.nchunks > wave ? (a.nchunks - wave + 3) >> 2 : 0;      // this wave's chunks: wave, wave+4, ...
+
+    const unsigned char* xg = reinterpret_cast<const unsigned char*>(a.x) + h * 16;
+    const unsigned char* wg = reinterpret_cast<const unsigned char*>(a.w) + (long long)(cobase + l31) * 64 + h * 16;
+    const long long xplane = a.M * 64;
+    const long long wtap = (long long)a.CoutPad * 64;
+
+    Frag fa[DEPTH][TAPS][TCO][2], fb[DEPTH][TAPS][TPOS][2];
+    f32x16 acc[TCO][TPOS];
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int j = 0; j < TPOS; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#define ADK_KS_LOAD(D_, TAP_, C_)                                                                           \
+    {                                                                                                        \
+        const int kc_ = wave + 4 * (C_);                                                                     \
+        const unsigned char* wp_ = wg + ((long long)kc_ * TAPS + (TAP_)) * wtap;                             \
+        const unsigned char* xp_ = xg + kc_ * xplane;                                                        \
+        _Pragma("unroll") for (int i = 0; i < TCO; ++i)                                                      \
+            _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                    \
+                fa[D_][TAP_][i][s] = *reinterpret_cast<const Frag*>(wp_ + i * 2048 + s * 32);                \
+        _Pragma("unroll") for (int j = 0; j < TPOS; ++j) {                                                   \
+            int row_ = mrow0 + j * 32 + l31 + (TAP_);                                                        \
+            row_ = row_ > mlast ? mlast : row_;          /* rows past the tensor only feed masked columns */ \
+            _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                    \
+                fb[D_][TAP_][j][s] = *reinterpret_cast<const Frag*>(xp_ + (long long)row_ * 64 + s * 32);    \
+        }                                                                                                    \
+    }
+
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < nck) {
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) ADK_KS_LOAD(d, tap, d)
+        }
+
+    for (int c0 = 0; c0 < nck; c0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int c = c0 + d;
+            if (c < nck) {
+#pragma unroll
+                for (int tap = 0; tap < TAPS; ++tap) {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                            for (int j = 0; j < TPOS; ++j) Mma<T>::run(fa[d][tap][i][s], fb[d][tap][j][s], acc[i][j]);
+                    if (c + DEPTH < nck) ADK_KS_LOAD(d, tap, c + DEPTH)     // refill the registers just consumed
+                }
+            }
+        }
+    }
+#undef ADK_KS_LOAD
+
+    // ---- cross-wave reduction: red[src wave][sub-tile][g][lane] (float4), summed in wave order ----
+    float4* red = reinterpret_cast<float4*>(smem);
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int j = 0; j < TPOS; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                red[((wave * S + i * TPOS + j) * 4 + g) * 64 + lane] =
+                    make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+    __syncthreads();
+
+    // wave w now owns D[co = cobase + 32 i + 8 w + 4 h + e][pos = l0 + 32 j + l31]
+    TO* yg = reinterpret_cast<TO*>(a.y);
+    const TO* rg = reinterpret_cast<const TO*>(a.residual);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < TPOS; ++j) {
+        const int l = l0 + j * 32 + l31;
+        const bool lvalid = l < a.L;
+        const long long m = (long long)b * a.Lp + a.P + l;
+#pragma unroll
+        for (int i = 0; i < TCO; ++i) {
+            const int co = cobase + i * 32 + 8 * wave + 4 * h;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sw = 0; sw < 4; ++sw) {
+                const float4 p = red[((sw * S + i * TPOS + j) * 4 + wave) * 64 + lane];
+                v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
+            }
+            if (a.bias) {
+                const float4 bb = *reinterpret_cast<const float4*>(a.bias + co);
+                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+            }
+            if (lvalid && co < a.Cout_alloc) {
+                const long long off = (((long long)(co / CBO) * a.M + m) * CBO) + (co % CBO);
+                if (rg) {
+                    float rr[4];
+                    load4(rg + off, rr);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rr[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s1 += v[e]; s2 += v[e] * v[e]; }
+                store4(yg + off, v);
+            }
+        }
+    }
+
+    // halo rows of the output: zeroed by the first / last tile of each sample
+    if (t == 0 || t == a.tps - 1) {
+        const int plane0 = cobase / CBO;
+        const int cend = cobase + BN < a.Cout_alloc ? cobase + BN : a.Cout_alloc;
+        const int nplanes = (cend + CBO - 1) / CBO - plane0;
+        const int per = a.P * 4;
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        unsigned char* yb = reinterpret_cast<unsigned char*>(a.y);
+        for (int p = tid; p < nplanes * per; p += 256) {
+            const int pl = plane0 + p / per, rem = p % per, row = rem >> 2, q = rem & 3;
+            const long long mh = (long long)b * a.Lp + row;
+            if (t == 0) *reinterpret_cast<uint4*>(yb + ((long long)pl * a.M + mh) * 64 + q * 16) = z;
+            if (t == a.tps - 1)
+                *reinterpret_cast<uint4*>(yb + ((long long)pl * a.M + mh + a.P + a.L) * 64 + q * 16) = z;
+        }
+    }
+
+    if (a.partials) {
+        block_sum2(s1, s2, reinterpret_cast<float*>(smem));     // starts with a barrier: the reads of `red` are done
+        if (tid == 0) {
+            float* dst = a.partials + ((long long)(b * a.tps + t) * a.ncot + cot) * 2;
+            dst[0] = s1; dst[1] = s2;
+        }
+    }
+}
+
+template <typename T, typename TO, int TAPS, int TCO, int TPOS>
+static int launch_ks(const adk_op& op, hipStream_t st)
+{
+    constexpr int DEPTH = TAPS == 1 ? 4 : (TCO * TPOS == 1 ? 2 : 1);
+    ConvArgs a;
+    conv_fill_args(op, TCO * 32, TPOS * 32, a);
+    const size_t lds = (size_t)TCO * TPOS * 16384;
+    hipLaunchKernelGGL((conv_ksplit_kernel<T, TO, TAPS, TCO, TPOS, DEPTH>), dim3(a.nblk), dim3(256), lds, st, a);
+    return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
+}
+
+template <typename T, typename TO, int TAPS>
+static int launch_ks_tiles(const adk_op& op, hipStream_t st)
+{
+    const ConvTile t = conv_tile(op);
+    if (t.bn == 32 && t.bm == 32) return launch_ks<T, TO, TAPS, 1, 1>(op, st);
+    if (t.bn == 32 && t.bm == 64) return launch_ks<T, TO, TAPS, 1, 2>(op, st);
+    if (t.bn == 64 && t.bm == 64) return launch_ks<T, TO, TAPS, 2, 2>(op, st);
+    return ADK_EINVAL;
+}
+
+template <typename T, typename TO>
+static int launch_ks_taps(const adk_op& op, hipStream_t st)
+{
+    if (op.taps == 1) return launch_ks_tiles<T, TO, 1>(op, st);
+    if (op.taps == 5) return launch_ks_tiles<T, TO, 5>(op, st);
+    return ADK_EINVAL;
+}
+
+int launch_conv_ksplit(const adk_op& op, hipStream_t st)
+{
+    if (op.dtype == ADK_F32) return launch_ks_taps<float, float>(op, st);
+    if (op.flags & ADK_FLAG_OUT_F32) return launch_ks_taps<bf16_t, float>(op, st);
+    return launch_ks_taps<bf16_t, bf16_t>(op, st);
+}

@@ -12,49 +12,7 @@
 //   bf16: v_mfma_f32_32x32x16_bf16 (fp32 accumulate);  f32: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain).
 // Epilogue: + bias, (+ residual), per-tile (sum, sumsq) partials for the following GroupNorm(1,C)
 // (deterministic: fixed-order tree, no atomics), halo rows of the output zeroed by the edge tiles.
-#include "adk_common.h"
-
-struct ConvArgs {
-    const void* x; const void* w; const float* bias; const void* residual; void* y; float* partials;
-    int B, L, P, Lp;
-    long long M;
-    int nchunks, Cout_alloc, CoutPad, tps, ncot;
-    unsigned nblk;
-};
-
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-    typedef bf16x8 Frag;
-    static __device__ __forceinline__ void run(const Frag& a, const Frag& b, f32x16& c) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-    }
-};
-template <> struct Mma<float> {
-    typedef f32x4 Frag;
-    static __device__ __forceinline__ void run(const Frag& a, const Frag& b, f32x16& c) {
-        // lane (r, h) holds k = 4h + {0,1,2,3} of this 8-wide k group for both operands
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], c, 0, 0, 0);
-    }
-};
-
-__device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
-    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-}
-__device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
-    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-}
-__device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
-    const float4 t = *reinterpret_cast<const float4*>(p);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-}
-__device__ __forceinline__ void load4(const bf16_t* p, float (&v)[4]) {
-    const uint2 t = *reinterpret_cast<const uint2*>(p);
-    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
-}
+#include "conv_common.h"
 
 template <typename TO, int BN, int BM, int WPOS, int TCO, int TPOS>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TCO][TPOS], unsigned char* smem,
@@ -240,13 +198,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_simple_kernel(const ConvArgs
 // ------------------------------------------------------------------------------------------------
 // Pipelined variant (co tile 128): the K loop runs in PHASES of one (channel chunk, tap) each.  The
 // unit of prefetch is one tap's weight tile W(kc, tap) (128 rows x 64 B = 8 KiB = 2 LDS-DMA instructions
-// per wave) held in a ring of D+1 slots; the activation tile X(kc) (BM + taps - 1 rows, shared by all
+// per wave) held in a ring of K+1 slots; the activation tile X(kc) (BM + taps - 1 rows, shared by all
 // taps of the chunk) is double-buffered and issued just ahead of W(kc, 0).  Every wave issues the same
-// number of LDS-DMA instructions per unit, so "unit g has landed" is one counted s_waitcnt vmcnt(N)
-// (N = this wave's instructions issued AFTER unit g, a compile-time constant per tap) followed by one
-// raw s_barrier per phase; D units stay in flight across barriers (never vmcnt(0) in steady state).
-//   phase g:  wait unit g (counted) -> s_barrier -> issue unit g+D (into the slot phase g-1 just
-//             released) -> ds_read fragments + MFMAs of (kc, tap).
+// number of LDS-DMA instructions per unit, so "unit u has landed" is one counted s_waitcnt vmcnt(N)
+// (N = this wave's instructions issued AFTER unit u, a compile-time constant per tap) followed by one
+// raw s_barrier per phase; K-2 units stay in flight across barriers (never vmcnt(0) in steady state).
+// Fragments are register double-buffered ACROSS the barrier so no ds_read latency sits in front of an
+// MFMA group:
+//   phase g:  ds_read frags(g, k-step 1) | MFMAs(g, k-step 0) | wait unit g+1 -> s_barrier -> issue unit
+//             g+K (into the slot phase g-1 released) | ds_read frags(g+1, k-step 0) | MFMAs(g, k-step 1)
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
@@ -255,11 +215,9 @@ template <typename T, typename TO, int TAPS, int WCO, int WPOS, int TCO, int TPO
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a)
 {
     constexpr int BN = WCO * TCO * 32, BM = WPOS * TPOS * 32;
-    static_assert(WCO * WPOS == 4 && BN == 128, "pipelined variant: 4 waves, 128-channel co tile");
-    constexpr int D = TAPS >= 3 ? 3 : 1;         // weight units in flight ahead of the consumer
-    // one slot more than the minimum: the slot refilled after phase g's barrier was last read in phase g-2,
-    // so a fragment read the compiler issued just ahead of a barrier can never race the refill
-    constexpr int RW = D + 2, RX = TAPS == 1 ? 3 : 2;
+    static_assert(WCO * WPOS == 4 && BN % 64 == 0, "pipelined variant: 4 waves, co tile a multiple of 64");
+    constexpr int K = TAPS >= 3 ? 4 : 2;         // unit g+K is issued during phase g
+    constexpr int RW = K + 1, RX = TAPS == 1 ? K + 1 : 2;
     constexpr int XROWS = BM + TAPS - 1;
     constexpr int XI = (XROWS + 63) / 64;        // X LDS-DMA instructions per wave (uniform; tile padded)
     constexpr int WI = BN / 64;                  // W LDS-DMA instructions per wave per unit
@@ -331,33 +289,56 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a)
     const int xfrag = (wpos * TPOS * 32 + l31) * 64;
     const int wsw = (l31 >> 2) & 3;
 
-#pragma unroll
-    for (int u = 0; u < D; ++u)
-        if (u < total) issue_unit(u);
+#define ADK_LOAD_FRAGS(AF_, BF_, WT_, XT_, XSW_, S_)                                                        \
+    {                                                                                                        \
+        const int p_ = 2 * (S_) + h;                                                                         \
+        _Pragma("unroll") for (int i = 0; i < TCO; ++i)                                                      \
+            AF_[i] = *reinterpret_cast<const Frag*>((WT_) + i * 2048 + ((p_ ^ wsw) << 4));                   \
+        _Pragma("unroll") for (int j = 0; j < TPOS; ++j)                                                     \
+            BF_[j] = *reinterpret_cast<const Frag*>((XT_) + j * 2048 + ((p_ ^ (XSW_)) << 4));                \
+    }
+#define ADK_MMA_ALL(AF_, BF_)                                                                                \
+    _Pragma("unroll") for (int i = 0; i < TCO; ++i)                                                          \
+        _Pragma("unroll") for (int j = 0; j < TPOS; ++j) Mma<T>::run(AF_[i], BF_[j], acc[i][j]);
 
-// instructions this wave issued after unit (kc, TAP_) when phase (kc, TAP_) starts: units +1 .. +D-1
+    Frag a0[TCO], b0[TPOS], a1[TCO], b1[TPOS];
+
+    // prologue: units 0..K-1 in flight, wait for unit 0, first fragments
+#pragma unroll
+    for (int u = 0; u < K; ++u)
+        if (u < total) issue_unit(u);
+    {
+        constexpr int n0 = []() { int n = 0; for (int u = 1; u < K; ++u) n += WI + (u % TAPS == 0 ? XI : 0); return n; }();
+        if (total >= K) wait_vmcnt<n0>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        ADK_LOAD_FRAGS(a0, b0, ws + wfrag, xs + xfrag, wsw, 0)
+    }
+
+// n_mid / n_last: LDS-DMA instructions this wave has issued after unit g+1 when phase g waits for it
 #define ADK_PHASE(TAP_)                                                                                      \
     if constexpr (TAP_ < TAPS) {                                                                             \
-        constexpr int n_mid = []() { int n = 0; for (int u = 1; u < D; ++u) n += WI + ((TAP_ + u) % TAPS == 0 ? XI : 0); return n; }(); \
-        constexpr int n_last = []() { int n = 0; for (int u = 1; u < D; ++u) n += (TAP_ + u < TAPS) ? WI : 0; return n; }();          \
-        if (last) wait_vmcnt<n_last>(); else wait_vmcnt<n_mid>();                                            \
-        __builtin_amdgcn_s_barrier();                                                                        \
-        asm volatile("" ::: "memory");                                                                       \
+        constexpr int n_mid = []() { int n = 0; for (int u = 2; u < K; ++u) n += WI + ((TAP_ + u) % TAPS == 0 ? XI : 0); return n; }(); \
+        constexpr int n_last = []() { int n = 0; for (int u = 2; u < K; ++u) n += (TAP_ + u < TAPS) ? WI : 0; return n; }();          \
         const int g_ = kc * TAPS + TAP_;                                                                     \
-        if (g_ + D < total) issue_unit(g_ + D);                                                              \
-        const unsigned char* wt_ = ws + (g_ % RW) * WBYTES + wfrag;                                          \
-        const unsigned char* xt_ = xs + (kc % RX) * XBYTES + xfrag + TAP_ * 64;                              \
-        const int xsw_ = ((l31 + TAP_) >> 2) & 3;                                                            \
-        _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                   \
-            const int p_ = 2 * s_ + h;                                                                       \
-            Frag af_[TCO], bf_[TPOS];                                                                        \
-            _Pragma("unroll") for (int i = 0; i < TCO; ++i)                                                  \
-                af_[i] = *reinterpret_cast<const Frag*>(wt_ + i * 2048 + ((p_ ^ wsw) << 4));                 \
-            _Pragma("unroll") for (int j = 0; j < TPOS; ++j)                                                 \
-                bf_[j] = *reinterpret_cast<const Frag*>(xt_ + j * 2048 + ((p_ ^ xsw_) << 4));                \
-            _Pragma("unroll") for (int i = 0; i < TCO; ++i)                                                  \
-                _Pragma("unroll") for (int j = 0; j < TPOS; ++j) Mma<T>::run(af_[i], bf_[j], acc[i][j]);     \
+        {                                                                                                    \
+            const unsigned char* wt_ = ws + (g_ % RW) * WBYTES + wfrag;                                      \
+            const unsigned char* xt_ = xs + (kc % RX) * XBYTES + xfrag + TAP_ * 64;                          \
+            ADK_LOAD_FRAGS(a1, b1, wt_, xt_, ((l31 + TAP_) >> 2) & 3, 1)                                     \
         }                                                                                                    \
+        ADK_MMA_ALL(a0, b0)                                                                                  \
+        if (g_ + 1 < total) {                                                                                \
+            if (last) wait_vmcnt<n_last>(); else wait_vmcnt<n_mid>();                                        \
+            __builtin_amdgcn_s_barrier();                                                                    \
+            asm volatile("" ::: "memory");                                                                   \
+            if (g_ + K < total) issue_unit(g_ + K);                                                          \
+            constexpr int nt_ = (TAP_ + 1) % TAPS;                                                           \
+            const int nkc_ = kc + (TAP_ + 1 == TAPS ? 1 : 0);                                                \
+            const unsigned char* wt_ = ws + ((g_ + 1) % RW) * WBYTES + wfrag;                                \
+            const unsigned char* xt_ = xs + (nkc_ % RX) * XBYTES + xfrag + nt_ * 64;                         \
+            ADK_LOAD_FRAGS(a0, b0, wt_, xt_, ((l31 + nt_) >> 2) & 3, 0)                                      \
+        }                                                                                                    \
+        ADK_MMA_ALL(a1, b1)                                                                                  \
     }
 
     for (int kc = 0; kc < a.nchunks; ++kc) {
@@ -365,6 +346,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a)
         ADK_PHASE(0) ADK_PHASE(1) ADK_PHASE(2) ADK_PHASE(3) ADK_PHASE(4)
     }
 #undef ADK_PHASE
+#undef ADK_LOAD_FRAGS
+#undef ADK_MMA_ALL
     __syncthreads();      // all fragment reads done before the epilogue reuses LDS for its reduction
 
     conv_epilogue<TO, BN, BM, WPOS, TCO, TPOS>(a, acc, smem, b, t, cot, cobase, l0, tid, l31, h, wco, wpos);
@@ -375,20 +358,19 @@ template <typename T, typename TO, int TAPS, int WCO, int WPOS, int TCO, int TPO
 static int launch_variant(const adk_op& op, hipStream_t st)
 {
     constexpr int BN = WCO * TCO * 32, BM = WPOS * TPOS * 32;
-    constexpr int CB = ElemTraits<T>::CB, CBO = ElemTraits<TO>::CB;
     ConvArgs a;
-    a.x = op.x; a.w = op.w; a.bias = reinterpret_cast<const float*>(op.bias); a.residual = op.residual; a.y = op.y; a.partials = op.partials_out;
-    a.B = op.B; a.L = op.L; a.P = op.P; a.Lp = op.L + 2 * op.P; a.M = (long long)op.B * a.Lp;
-    a.nchunks = op.Cin / CB;
-    a.Cout_alloc = (op.Cout + CBO - 1) / CBO * CBO;
-    a.CoutPad = op.CoutPad;
-    a.tps = (op.L + BM - 1) / BM;
-    a.ncot = op.CoutPad / BN;
-    a.nblk = (unsigned)(op.B * a.tps * a.ncot);
-    if constexpr (BN == 128) {
-        constexpr int D = TAPS >= 3 ? 3 : 1;
+    conv_fill_args(op, BN, BM, a);
+    if constexpr (BN >= 128) {
+        constexpr int K = TAPS >= 3 ? 4 : 2;
         constexpr int XI = (BM + TAPS - 1 + 63) / 64;
-        const size_t lds = (size_t)(TAPS == 1 ? 3 : 2) * XI * 4096 + (size_t)(D + 2) * BN * 64;
+        const size_t lds = (size_t)(TAPS == 1 ? K + 1 : 2) * XI * 4096 + (size_t)(K + 1) * BN * 64;
+        static bool attr_set = false;             // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, TO, TAPS, WCO, WPOS, TCO, TPOS>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return ADK_ELAUNCH;
+            attr_set = true;
+        }
         hipLaunchKernelGGL((conv_mfma_kernel<T, TO, TAPS, WCO, WPOS, TCO, TPOS>), dim3(a.nblk), dim3(256), lds, st, a);
     } else {
         const size_t lds = (size_t)((BM + TAPS - 1 + 15) / 16) * 1024 + (size_t)TAPS * BN * 64;
@@ -397,35 +379,52 @@ static int launch_variant(const adk_op& op, hipStream_t st)
     return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
 }
 
-// tile-shape selection (host); adk_conv_cotile / adk_conv_postile / adk_partials_count report it
-static inline int conv_bn(int Cout) { return Cout <= 32 ? 32 : 128; }
-static inline int conv_bm(const adk_op& op)
+void conv_fill_args(const adk_op& op, int BN, int BM, ConvArgs& a)
 {
-    if (conv_bn(op.Cout) == 32) return 128;
-    if (op.L <= 32) return 32;
-    if (op.L <= 64) return 64;
-    // wide tile (W amortised over 256 positions) only while it still leaves >= 2 blocks per CU
+    const int CB = op.dtype == ADK_F32 ? 16 : 32;
+    const int CBO = (op.dtype == ADK_F32 || (op.flags & ADK_FLAG_OUT_F32)) ? 16 : 32;
+    a.x = op.x; a.w = op.w; a.bias = reinterpret_cast<const float*>(op.bias); a.residual = op.residual; a.y = op.y; a.partials = op.partials_out;
+    a.B = op.B; a.L = op.L; a.P = op.P; a.Lp = op.L + 2 * op.P; a.M = (long long)op.B * a.Lp;
+    a.nchunks = op.Cin / CB;
+    a.Cout_alloc = (op.Cout + CBO - 1) / CBO * CBO;
+    a.CoutPad = op.CoutPad;
+    a.tps = (op.L + BM - 1) / BM;
+    a.ncot = op.CoutPad / BN;
+    a.nblk = (unsigned)(op.B * a.tps * a.ncot);
+}
+
+// tile-shape selection (host); adk_conv_cotile / adk_conv_postile / adk_partials_count report it.
+static inline int conv_bn(int Cout) { return Cout <= 32 ? 32 : 128; }
+ConvTile conv_tile(const adk_op& op)
+{
+    if (conv_bn(op.Cout) == 32) return {32, 128, false};
+    // short levels: too few (co, pos) tiles to fill 256 CUs and a serial K loop of up to 400 phases ->
+    // small tiles whose K range is split over the block's 4 waves (conv_ksplit.hip)
+    if (op.L <= 32) return {32, 32, true};
+    if (op.L <= 64) return {32, 64, true};
+    if (op.L <= 256) return {64, 64, true};
+    // wide tile (W amortised over 256 positions) only while it still leaves >= 2 blocks per CU.
+    // (256co x 256pos and 128co x 512pos one-wave-per-SIMD tiles were measured 7-20 % slower: r01 notes.)
     const long long wide = (long long)op.B * ((op.L + 255) / 256) * (op.CoutPad / 128);
-    return (op.L >= 256 && wide >= 512) ? 256 : 128;
+    return {128, (op.L >= 256 && wide >= 512) ? 256 : 128, false};
 }
 
 int conv_cotile(int Cout) { return conv_bn(Cout); }
-int conv_postile(const adk_op& op) { return conv_bm(op); }
+int conv_postile(const adk_op& op) { return conv_tile(op).bm; }
+int conv_cotile_used(const adk_op& op) { return conv_tile(op).bn; }
 int conv_partials_count(const adk_op& op)
 {
-    const int bm = conv_bm(op);
-    return ((op.L + bm - 1) / bm) * (op.CoutPad / conv_bn(op.Cout));
+    const ConvTile t = conv_tile(op);
+    return ((op.L + t.bm - 1) / t.bm) * (op.CoutPad / t.bn);
 }
 
 template <typename T, typename TO, int TAPS>
 static int launch_tiles(const adk_op& op, hipStream_t st)
 {
-    const int bn = conv_bn(op.Cout), bm = conv_bm(op);
-    if (bn == 32) return launch_variant<T, TO, TAPS, 1, 4, 1, 1>(op, st);
-    if (bm == 256) return launch_variant<T, TO, TAPS, 2, 2, 2, 4>(op, st);
-    if (bm == 128) return launch_variant<T, TO, TAPS, 2, 2, 2, 2>(op, st);
-    if (bm == 64) return launch_variant<T, TO, TAPS, 2, 2, 2, 1>(op, st);
-    return launch_variant<T, TO, TAPS, 4, 1, 1, 1>(op, st);
+    const ConvTile t = conv_tile(op);
+    if (t.bn == 32) return launch_variant<T, TO, TAPS, 1, 4, 1, 1>(op, st);
+    if (t.bm == 256) return launch_variant<T, TO, TAPS, 2, 2, 2, 4>(op, st);
+    return launch_variant<T, TO, TAPS, 2, 2, 2, 2>(op, st);
 }
 
 template <typename T, typename TO>
@@ -438,6 +437,7 @@ static int launch_taps(const adk_op& op, hipStream_t st)
 
 int launch_conv(const adk_op& op, hipStream_t st)
 {
+    if (conv_tile(op).ksplit) return launch_conv_ksplit(op, st);
     if (op.dtype == ADK_F32) return launch_taps<float, float>(op, st);
     if (op.flags & ADK_FLAG_OUT_F32) return launch_taps<bf16_t, float>(op, st);
     return launch_taps<bf16_t, bf16_t>(op, st);

@@ -164,7 +164,7 @@ class _Plan:
             ptrs["residual"] = ("arena", residual.off)
         flags = _lib.FLAG_OUT_F32 if (out_f32 and self.dtype != torch.float32) else 0
         op = self._emit(_lib.OP_CONV, ptrs, flags=flags, L=x.L, Cin=cin_alloc, Cout=Cout, CoutPad=cout_pad, taps=taps)
-        self.meta[-1].update(taps=taps, L=x.L, cin=w.shape[1], cout=Cout, cotile=bn,
+        self.meta[-1].update(taps=taps, L=x.L, cin=w.shape[1], cout=Cout, cotile=self.lib.adk_conv_cotile_used(ctypes.byref(op)),
                              postile=self.lib.adk_conv_postile(ctypes.byref(op)),
                              flops=2.0 * w.shape[1] * Cout * taps * x.L * self.B)
         part = None

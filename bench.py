@@ -67,8 +67,8 @@ def conv_roofline(model, B, dtype, dev, reps=3):
     stream = torch.cuda.current_stream(dev)
     groups = {}
     for i, m in enumerate(plan.meta):
-        if m["kind"] == _lib.OP_CONV and m["taps"] == 5 and m["cotile"] == 128:
-            groups.setdefault(m["postile"], []).append(i)
+        if m["kind"] == _lib.OP_CONV and m["taps"] == 5 and m["cotile"] >= 128:
+            groups.setdefault(f'{m["cotile"]}co x {m["postile"]}pos', []).append(i)
     timed = set(i for g in groups.values() for i in g)
     ms = {i: 0.0 for i in timed}
     for r in range(reps + 1):
@@ -95,7 +95,7 @@ def conv_roofline(model, B, dtype, dev, reps=3):
                    "tflops": fl / (tm * 1e-3) / 1e12, "ms_per_call": tm}
     dom = max(per, key=lambda k: per[k]["flop_per_call"])
     d = per[dom]
-    return {"bound": "mfma", "kernel": f"conv_mfma_kernel<{key}, taps=5, tile 128co x {dom}pos>",
+    return {"bound": "mfma", "kernel": f"conv_mfma_kernel<{key}, taps=5, tile {dom}>",
             "achieved": d["tflops"], "peak": PEAK[key], "unit": "TFLOP/s", "frac": d["tflops"] / PEAK[key],
             "traffic": None, "launches_per_call": d["launches_per_call"], "avg_launch_us": d["avg_launch_us"],
             "flop_per_launch_avg": d["flop_per_call"] / d["launches_per_call"],

@@ -90,6 +90,8 @@ int adk_partials_count(const adk_op *op);
 
 /* Positions per block (32, 64, 128 or 256) the conv kernel will use for this op (needs B, L, Cout, CoutPad). */
 int adk_conv_postile(const adk_op *op);
+/* Output channels per block (32, 128 or 256) the conv kernel will use for this op. */
+int adk_conv_cotile_used(const adk_op *op);
 
 /* Co-tile (rows of packed weight must be a multiple of this) the conv kernel will use. */
 int adk_conv_cotile(int dtype, int Cout, int L);

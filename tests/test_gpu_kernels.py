@@ -53,6 +53,12 @@ CONV_CASES = [
     (1, 1024, 32, 32, 1, True, False),
     (8, 16384, 32, 128, 5, True, False),   # wide (256-position) tile variant
     (9, 16500, 64, 256, 5, True, True),    # wide tile, ragged last tile, 2 co tiles
+    # short levels: K split over the 4 waves (conv_ksplit.hip): 32x32, 32x64 and 64x64 tiles
+    (16, 8, 512, 512, 5, True, False),     # deepest level of the uncond model
+    (1, 16, 32, 64, 5, True, True),        # one channel chunk: three waves contribute zeros
+    (3, 40, 160, 96, 1, False, True),      # 5 chunks (not a multiple of 4 waves), ragged 64-position tile
+    (2, 128, 1024, 512, 5, True, False),   # concat input (32 chunks), 64x64 tiles
+    (2, 250, 96, 1536, 1, True, False),    # qkv projection shape, ragged last tile
 ]
 
 
@@ -255,6 +261,34 @@ def test_attention_vs_golden(env, golden_blocks, dt, s):
     torch.cuda.synchronize()
     y = layout.from_cpl(od, Cc).cpu()[:, :, P:P + L]
     assert rel_err(y, ref) <= (1e-5 if dt == "f32" else 2e-2)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("B,heads,s", [(2, 2, 8), (3, 1, 100), (1, 3, 257), (2, 2, 1024), (1, 2, 4096), (1, 1, 1000)])
+def test_attention_core(env, dt, B, heads, s):
+    """adk_attn1d alone (softmax(q k^T / sqrt(32)) v per head) vs an fp32 CPU reference on the same (rounded)
+    inputs: ragged key tiles, sequences from 8 to 4096 (the long-context config), both query-tile widths of
+    the MFMA kernel.  Scores are spread (|q.k| up to ~8) so the online-softmax rescale branch is exercised,
+    and one key row per head is spiked to force a late running-max jump."""
+    lib, _lib, layout, dev = env
+    dtype, adk, _ = DT[dt]
+    if dt == "f32" and s > 1100:
+        pytest.skip("the exact-fp32 VALU kernel is only used at the short levels of the fp32 parity path")
+    Cc, P, cb = heads * 32, 2, layout.chunk(dtype)
+    g = torch.Generator().manual_seed(s * 7 + heads)
+    qkv = torch.randn(B, 3 * Cc, s, generator=g) * 1.3
+    qkv[:, Cc:2 * Cc, (3 * s) // 4] *= 4.0                      # a late key that dominates many rows
+    qkvq = quant(qkv, dtype)
+    q, k, v = [t.view(B, heads, 32, s).transpose(2, 3) for t in qkvq.split(Cc, dim=1)]
+    ref = F.scaled_dot_product_attention(q.double(), k.double(), v.double()).float().transpose(2, 3).reshape(B, Cc, s)
+    qd = layout.to_cpl(qkv.to(dev), dtype, P)
+    yd = torch.full((Cc // cb, B, s + 2 * P, cb), 5.0, dtype=dtype, device=dev)
+    assert lib.adk_attn1d(adk, B, s, P, Cc, qd.data_ptr(), yd.data_ptr(), sp()) == 0, lib.adk_last_error()
+    torch.cuda.synchronize()
+    full = layout.from_cpl(yd, Cc).cpu()
+    y = full[:, :, P:P + s]
+    assert rel_err(y, ref) <= (2e-5 if dt == "f32" else 1.5e-2)
+    assert float(full[:, :, :P].abs().max()) == 0.0 and float(full[:, :, P + s:].abs().max()) == 0.0, "halo rows not zero"
 
 
 PQMF_CASES = [(1, 70, 32), (2, 70, 32), (2, 70, 4), (2, 70, 16), (2, 100, 32)]

@@ -91,6 +91,26 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
+// GELU for the bf16 path: erf through Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, far below bf16
+// rounding), 15 VALU instructions (2 transcendental) instead of ~35 for erff: with exact erff the GroupNorm
+// pass is VALU-bound at ~5.1 TB/s, not HBM-bound.  gelu(v) = v - v*E/2 (v >= 0), v*E/2 (v < 0),
+// E = erfc(|v|/sqrt 2) = poly(t) exp(-z^2), t = 1/(1 + p z).
+__device__ __forceinline__ float gelu_fast(float v) {
+    const float z = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    float p = 0.5f * 1.061405429f;
+    p = __builtin_fmaf(p, t, 0.5f * -1.453152027f);
+    p = __builtin_fmaf(p, t, 0.5f * 1.421413741f);
+    p = __builtin_fmaf(p, t, 0.5f * -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.5f * 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
+    const float r = v * (p * t * e);
+    return v >= 0.f ? v - r : r;
+}
+template <typename T> __device__ __forceinline__ float gelu_for(float v);
+template <> __device__ __forceinline__ float gelu_for<float>(float v) { return gelu_erf(v); }
+template <> __device__ __forceinline__ float gelu_for<bf16_t>(float v) { return gelu_fast(v); }
+
 // XCD-aware bijective remap of a 1-D block id: consecutive logical ids share an XCD (8 XCDs).
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
     const unsigned q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, slot = bid >> 3;

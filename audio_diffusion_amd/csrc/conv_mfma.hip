@@ -21,6 +21,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
 {
     constexpr int CBO = ElemTraits<TO>::CB;
     // ---- epilogue: lane (l31, h) holds D[co = 8g + 4h + e][pos = l31] in acc[..][4g + e] ----
+    // bf16 output: the two half-waves hold the two 8-byte halves of one 16-byte piece, so channel groups are
+    // processed in pairs (g, g+1) and exchanged with v_permlane32_swap: lanes h=0 then store channels
+    // 8g..8g+7, lanes h=1 channels 8g+8..8g+15, as ONE 16-byte store each (half the store instructions:
+    // the tail of this kernel is store-issue bound, not bandwidth bound).
     TO* yg = reinterpret_cast<TO*>(a.y);
     const TO* rg = reinterpret_cast<const TO*>(a.residual);
     float s1 = 0.f, s2 = 0.f;
@@ -31,27 +35,44 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
         const long long m = (long long)b * a.Lp + a.P + l;
 #pragma unroll
         for (int i = 0; i < TCO; ++i) {
+            const int co32 = cobase + (wco * TCO + i) * 32;
+            const bool ok = lvalid && co32 < a.Cout_alloc;      // Cout_alloc is a multiple of 32 when TO = bf16
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = cobase + (wco * TCO + i) * 32 + 8 * g + 4 * h;
-                float v[4];
+            for (int g0 = 0; g0 < 4; g0 += 2) {
+                float v[2][4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-                if (a.bias) {
-                    const float4 bb = *reinterpret_cast<const float4*>(a.bias + co);
-                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-                }
-                if (lvalid && co < a.Cout_alloc) {
-                    const long long off = (((long long)(co / CBO) * a.M + m) * CBO) + (co % CBO);
-                    if (rg) {
-                        float rr[4];
-                        load4(rg + off, rr);
+                for (int gg = 0; gg < 2; ++gg) {
+                    const int co = co32 + 8 * (g0 + gg) + 4 * h;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += rr[e];
+                    for (int e = 0; e < 4; ++e) v[gg][e] = acc[i][j][4 * (g0 + gg) + e];
+                    if (a.bias) {
+                        const float4 bb = *reinterpret_cast<const float4*>(a.bias + co);
+                        v[gg][0] += bb.x; v[gg][1] += bb.y; v[gg][2] += bb.z; v[gg][3] += bb.w;
                     }
+                    if (lvalid && co < a.Cout_alloc) {
+                        const long long off = (((long long)(co / CBO) * a.M + m) * CBO) + (co % CBO);
+                        if (rg) {
+                            float rr[4];
+                            load4(rg + off, rr);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { s1 += v[e]; s2 += v[e] * v[e]; }
-                    store4(yg + off, v);
+                            for (int e = 0; e < 4; ++e) v[gg][e] += rr[e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { s1 += v[gg][e]; s2 += v[gg][e] * v[gg][e]; }
+                        if constexpr (sizeof(TO) == 4) store4(yg + off, v[gg]);
+                    }
+                }
+                if constexpr (sizeof(TO) == 2) {
+                    uint32_t ax = pack_bf16x2(v[0][0], v[0][1]), ay = pack_bf16x2(v[0][2], v[0][3]);
+                    uint32_t bx = pack_bf16x2(v[1][0], v[1][1]), by = pack_bf16x2(v[1][2], v[1][3]);
+                    // swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second (all lanes active here)
+                    const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                    const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                    if (ok) {
+                        const int co = co32 + 8 * g0 + 8 * h;   // h=0: [own g0 | partner's g0], h=1: [partner's g0+1 | own g0+1]
+                        const long long off = (((long long)(co / CBO) * a.M + m) * CBO) + (co % CBO);
+                        *reinterpret_cast<uint4*>(yg + off) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                    }
                 }
             }
         }

@@ -1,4 +1,5 @@
-// GroupNorm(1,C) apply + exact GELU + residual add, one HBM-bound pass over a chunk-plane tensor.
+// GroupNorm(1,C) apply + GELU + residual add, one HBM-bound pass over a chunk-plane tensor.
+// GELU is the exact erf form: erff in the f32 path, a 1.5e-7-accurate erf in the bf16 path (adk_common.h).
 //
 // Replaces nn.GroupNorm(1,C) -> nn.GELU() -> (+ skip) of ResConvBlock (reference blocks/blocks.py:71-75,
 // 14-15) and the norm of SelfAttention1d (:107,115).  The per-sample statistics arrive as (sum, sumsq)
@@ -43,19 +44,18 @@ __global__ __launch_bounds__(256) void gn_kernel(const GnArgs a)
 
     const int lbeg = rb * a.RB, lend = (lbeg + a.RB < a.L) ? lbeg + a.RB : a.L;
     float s1 = 0.f, s2 = 0.f;
-    for (int l = lbeg + r0; l < lend; l += 64) {
-        const long long ro = (long long)(a.P + l) * 64;
+    auto body = [&](const uint4& xin, const uint4& rin, long long ro) {
         float f[NV];
-        piece_to_float(*reinterpret_cast<const uint4*>(xb + ro), f, T());
+        piece_to_float(xin, f, T());
         if (APPLY) {
 #pragma unroll
             for (int e = 0; e < NV; ++e) {
                 float v = f[e] * scale[e] + shift[e];
-                f[e] = GELU ? gelu_erf(v) : v;
+                f[e] = GELU ? gelu_for<T>(v) : v;
             }
             if (rbp) {
                 float r[NV];
-                piece_to_float(*reinterpret_cast<const uint4*>(rbp + ro), r, T());
+                piece_to_float(rin, r, T());
 #pragma unroll
                 for (int e = 0; e < NV; ++e) f[e] += r[e];
             }
@@ -63,6 +63,25 @@ __global__ __launch_bounds__(256) void gn_kernel(const GnArgs a)
         }
 #pragma unroll
         for (int e = 0; e < NV; ++e) { s1 += f[e]; s2 += f[e] * f[e]; }
+    };
+    constexpr int U = 4;                             // independent 16-byte loads in flight per thread
+    int l = lbeg + r0;
+    for (; l + 64 * (U - 1) < lend; l += 64 * U) {
+        uint4 xin[U], rin[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long ro = (long long)(a.P + l + 64 * u) * 64;
+            xin[u] = *reinterpret_cast<const uint4*>(xb + ro);
+            rin[u] = rbp ? *reinterpret_cast<const uint4*>(rbp + ro) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) body(xin[u], rin[u], (long long)(a.P + l + 64 * u) * 64);
+    }
+    for (; l < lend; l += 64) {
+        const long long ro = (long long)(a.P + l) * 64;
+        const uint4 xin = *reinterpret_cast<const uint4*>(xb + ro);
+        const uint4 rin = rbp ? *reinterpret_cast<const uint4*>(rbp + ro) : make_uint4(0, 0, 0, 0);
+        body(xin, rin, ro);
     }
     if (APPLY && (rb == 0 || rb == a.nrb - 1)) {      // halo rows of the output
         const uint4 z = make_uint4(0, 0, 0, 0);

@@ -3,7 +3,7 @@
 Public surface (same names as the reference):
     DiffusionAttnUnet1D                      decoders/diffusion_decoder.py:56-176
     sample, get_alphas_sigmas, alpha_sigma_to_t    diffusion/sampling.py:6-55
-    CachedPQMF                               diffusion/pqmf.py:236-302 (parameter container + design)
+    CachedPQMF                               diffusion/pqmf.py:236-302 (design + forward/inverse on libadk)
 Compute runs exclusively in libadk.so (hand-written gfx950 HIP kernels, C ABI in include/adk.h).
 """
 from .unet import DiffusionAttnUnet1D

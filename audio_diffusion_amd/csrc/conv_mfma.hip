@@ -424,10 +424,11 @@ ConvTile conv_tile(const adk_op& op)
     if (op.L <= 32) return {32, 32, true};
     if (op.L <= 64) return {32, 64, true};
     if (op.L <= 256) return {64, 64, true};
-    // wide tile (W amortised over 256 positions) only while it still leaves >= 2 blocks per CU.
-    // (256co x 256pos and 128co x 512pos one-wave-per-SIMD tiles were measured 7-20 % slower: r01 notes.)
-    const long long wide = (long long)op.B * ((op.L + 255) / 256) * (op.CoutPad / 128);
-    return {128, (op.L >= 256 && wide >= 512) ? 256 : 128, false};
+    // wide tile (W amortised over 256 positions) from L = 2048 up.  The choice depends on L only, never on B:
+    // the tile shape fixes the order in which GroupNorm partials are summed, and a sample's result must not
+    // depend on how many other samples share its launch (batch sharding across GPUs stays bit-exact).
+    // (256co x 256pos and 128co x 512pos one-wave-per-SIMD tiles were measured 7-20 % slower.)
+    return {128, op.L >= 2048 ? 256 : 128, false};
 }
 
 int conv_cotile(int Cout) { return conv_bn(Cout); }

@@ -88,3 +88,49 @@ class CachedPQMF(nn.Module):
         fw = self.forward_conv.weight.detach().to(device=device, dtype=torch.float32)
         iw = self.inverse_conv.weight.detach().to(device=device, dtype=torch.float32)
         return fw[:, 0, :].t().contiguous(), iw.permute(1, 2, 0).contiguous()
+
+    # ---- the reference's call interface (diffusion/pqmf.py:271-302), executed by libadk ----------------
+    def _filters(self, device):
+        key = str(device)
+        cache = self.__dict__.setdefault("_packed", {})
+        ver = (self.forward_conv.weight._version, self.inverse_conv.weight._version)
+        if key not in cache or cache[key][0] != ver:
+            cache[key] = (ver, self.packed_filters(device))
+        return cache[key][1]
+
+    @torch.no_grad()
+    def forward(self, x):
+        """[B, C, T] -> [B, C*M, T/M]: analysis conv (stride M, zero padding K//2), reverse_half sign
+        pattern, stereo folded channel -> batch -> channel (reference pqmf.py:271-283)."""
+        from . import _lib
+        if not x.is_cuda:
+            raise RuntimeError("CachedPQMF (MI355X build) runs on ROCm devices only; there is no CPU path")
+        B, C, T = x.shape
+        M = self.n_band
+        if T % M:
+            raise ValueError(f"T={T} is not a multiple of n_band={M}")
+        fwT, _ = self._filters(x.device)
+        xin = x.detach().to(torch.float32).contiguous()
+        y = torch.empty(B, C * M, T // M, device=x.device, dtype=torch.float32)
+        lib = _lib.load()
+        _lib.check(lib.adk_pqmf_analysis(B, C, T, M, fwT.shape[0], xin.data_ptr(), fwT.data_ptr(), y.data_ptr(),
+                                         torch.cuda.current_stream(x.device).cuda_stream), "adk_pqmf_analysis")
+        return y
+
+    @torch.no_grad()
+    def inverse(self, x):
+        """[B, C*M, N] -> [B, C, N*M] (reference pqmf.py:285-302); reconstruction is delayed by M samples."""
+        from . import _lib
+        if not x.is_cuda:
+            raise RuntimeError("CachedPQMF (MI355X build) runs on ROCm devices only; there is no CPU path")
+        B, CM, N = x.shape
+        M = self.n_band
+        if CM % M:
+            raise ValueError(f"channel count {CM} is not a multiple of n_band={M}")
+        _, iwT = self._filters(x.device)
+        xin = x.detach().to(torch.float32).contiguous()
+        y = torch.empty(B, CM // M, N * M, device=x.device, dtype=torch.float32)
+        lib = _lib.load()
+        _lib.check(lib.adk_pqmf_synthesis(B, CM // M, N, M, iwT.shape[1], xin.data_ptr(), iwT.data_ptr(), y.data_ptr(),
+                                          torch.cuda.current_stream(x.device).cuda_stream), "adk_pqmf_synthesis")
+        return y

@@ -244,6 +244,7 @@ class _Plan:
         self.free(n)
         y = self.tensor(x.C, x.L)
         self._emit(_lib.OP_ATTN, {"x": ("arena", qkv.off), "y": ("arena", y.off)}, L=x.L, Cin=x.C)
+        self.meta[-1].update(L=x.L, c=x.C, attn_flops=4.0 * x.L * x.L * x.C * self.B)      # QK^T + PV
         self.free(qkv)
         o, _ = self.conv(y, key + "out_proj", att.out_proj.weight, att.out_proj.bias, x.C, residual=x, out=out)
         self.free(y, x)

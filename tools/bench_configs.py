@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Denoiser-call timings for the BASELINE.json configs that are not bench.py's headline line:
+config 2 in fp32, config 3a / 3b (long context), config 4 (PQMF-banded) and the PQMF kernels alone.
+
+usage: python tools/bench_configs.py [--reps 5] [--only 3a,4]
+Prints one JSON line per config (ms per denoiser call, algorithmic TFLOP/s, audio-s/s at 100 DDIM steps).
+Synthetic inputs, random-init weights (seed 0)."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import audio_diffusion_amd as A
+from audio_diffusion_amd import _lib
+
+SR = 48000
+CONFIGS = {
+    "2-fp32": (dict(n_attn_layers=4), 16, 65536, torch.float32),
+    "2-bf16": (dict(n_attn_layers=4), 16, 65536, torch.bfloat16),
+    "3a": (dict(), 4, 262144, torch.bfloat16),
+    "3b": (dict(io_channels=2, pqmf_bands=16, depth=8, c_mults=[256, 256, 512, 512, 512, 512, 512, 512],
+                n_attn_layers=1), 4, 262144, torch.bfloat16),
+    "4": (dict(io_channels=2, pqmf_bands=32, depth=10, c_mults=[256, 256] + [512] * 8, n_attn_layers=2),
+          16, 131072, torch.bfloat16),
+}
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    names = [n for n in CONFIGS if not a.only or n in a.only.split(",")]
+    for name in names:
+        kw, B, T, dtype = CONFIGS[name]
+        torch.manual_seed(0)
+        m = A.DiffusionAttnUnet1D(**kw).to(dev).eval()
+        m.compute_dtype = dtype
+        x = torch.randn(B, 2, T, device=dev)
+        t = torch.full((B,), 0.5, device=dev)
+        plan = m.plan_for(B, T, dtype, dev)
+        out = torch.empty_like(x)
+        plan.bind(x.data_ptr(), t.data_ptr(), out.data_ptr())
+        st = torch.cuda.current_stream(dev)
+        ms = timed(lambda: plan.run(st.cuda_stream), a.reps)
+        flops = sum(mt.get("flops", 0.0) for mt in plan.meta)
+        attn = sum(mt.get("attn_flops", 0.0) for mt in plan.meta)
+        rec = {"config": name, "model": kw, "batch": B, "T": T, "dtype": str(dtype).split(".")[-1],
+               "params_M": sum(p.numel() for p in m.parameters()) / 1e6,
+               "ms_per_denoiser_call": ms, "conv_flop_per_call": flops, "attn_flop_per_call": attn,
+               "algorithmic_tflops": (flops + attn) / (ms * 1e-3) / 1e12,
+               "audio_s_per_s_at_100_steps": B * T / SR / (ms * 1e-3 * 100), "arena_GB": plan.peak / 1e9,
+               "n_ops": plan.n_ops}
+        print(json.dumps(rec), flush=True)
+        if name == "4":                                    # the filterbank kernels alone, [16, 2, 2^17], 32 bands
+            xx = torch.randn(16, 2, 131072, device=dev)
+            ms_a = timed(lambda: m.pqmf(xx), 20)
+            bands = m.pqmf(xx)
+            ms_s = timed(lambda: m.pqmf.inverse(bands), 20)
+            nbytes = 2 * xx.numel() * 4                    # read once + write once, fp32
+            print(json.dumps({"config": "4-pqmf-kernels", "shape": [16, 2, 131072], "bands": 32,
+                              "analysis_ms": ms_a, "synthesis_ms": ms_s,
+                              "analysis_GBps_algorithmic": nbytes / ms_a / 1e6,
+                              "synthesis_GBps_algorithmic": nbytes / ms_s / 1e6,
+                              "note": "timings include the output allocation of the Python wrapper"}), flush=True)
+        del m, plan
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

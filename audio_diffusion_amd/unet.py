@@ -166,7 +166,9 @@ class _Plan:
         op = self._emit(_lib.OP_CONV, ptrs, flags=flags, L=x.L, Cin=cin_alloc, Cout=Cout, CoutPad=cout_pad, taps=taps)
         self.meta[-1].update(taps=taps, L=x.L, cin=w.shape[1], cout=Cout, cotile=self.lib.adk_conv_cotile_used(ctypes.byref(op)),
                              postile=self.lib.adk_conv_postile(ctypes.byref(op)),
-                             flops=2.0 * w.shape[1] * Cout * taps * x.L * self.B)
+                             flops=2.0 * w.shape[1] * Cout * taps * x.L * self.B,
+                             bytes=float(self.B) * x.L * (cin_alloc * (4 if x.f32 else 2) + Cout * (4 if y.f32 else 2))
+                             + float(cin_alloc) * cout_pad * taps * (4 if x.f32 else 2))
         part = None
         if stats:
             n = self.lib.adk_partials_count(ctypes.byref(op))

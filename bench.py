@@ -95,13 +95,37 @@ def conv_roofline(model, B, dtype, dev, reps=3):
                    "tflops": fl / (tm * 1e-3) / 1e12, "ms_per_call": tm}
     dom = max(per, key=lambda k: per[k]["flop_per_call"])
     d = per[dom]
+    alg_bytes = sum(plan.meta[i]["bytes"] for i in groups[dom]) / len(groups[dom])
     return {"bound": "mfma", "kernel": f"conv_mfma_kernel<{key}, taps=5, tile {dom}>",
             "achieved": d["tflops"], "peak": PEAK[key], "unit": "TFLOP/s", "frac": d["tflops"] / PEAK[key],
-            "traffic": None, "launches_per_call": d["launches_per_call"], "avg_launch_us": d["avg_launch_us"],
+            "traffic": pmc_traffic(key, dom), "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
+            "separate --pmc passes, profiles/)", "algorithmic_bytes_per_launch": alg_bytes,
+            "launches_per_call": d["launches_per_call"], "avg_launch_us": d["avg_launch_us"],
             "flop_per_launch_avg": d["flop_per_call"] / d["launches_per_call"],
             "share_of_call_flop": d["flop_per_call"] / (6.899e11 * B),
             "other_tiles": {str(k): {"tflops": v["tflops"], "launches_per_call": v["launches_per_call"],
                                      "avg_launch_us": v["avg_launch_us"]} for k, v in per.items() if k != dom}}
+
+
+def pmc_traffic(key, tile):
+    """HBM bytes per launch of the dominant kernel from the committed counter summary (tools/run_pmc.sh ->
+    profiles/rNN/pmc_summary.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction).
+    bench.py cannot collect counters itself; null when no summary covers this kernel."""
+    import glob
+    import re
+    m = re.match(r"(\d+)co x (\d+)pos", tile)
+    if not m or key != "bf16":
+        return None
+    tpos = int(m.group(2)) // 64
+    mangled = f"_Z16conv_mfma_kernelIDF16bDF16bLi5ELi2ELi2ELi2ELi{tpos}EEv8ConvArgs"
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.json")), reverse=True):
+        try:
+            e = json.load(open(f)).get(mangled)
+        except (OSError, ValueError):
+            continue
+        if e and "hbm_bytes_per_launch" in e:
+            return e["hbm_bytes_per_launch"]
+    return None
 
 
 def _offset(ops, i):

@@ -21,9 +21,12 @@ __global__ __launch_bounds__(256, (TCO * TPOS >= 4 ? 1 : 2)) void conv_ksplit_ke
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
+    // co-tile-major logical order: after the XCD remap an XCD owns a contiguous range of co tiles, so each of
+    // the 8 L2s fetches only its share of the weights (which come from HBM on every denoiser call)
     const unsigned lid = xcd_remap(blockIdx.x, a.nblk);
-    const int cot = (int)(lid % (unsigned)a.ncot);
-    const unsigned r1 = lid / (unsigned)a.ncot;
+    const unsigned nbt = (unsigned)(a.B * a.tps);
+    const int cot = (int)(lid / nbt);
+    const unsigned r1 = lid % nbt;
     const int t = (int)(r1 % (unsigned)a.tps);
     const int b = (int)(r1 / (unsigned)a.tps);
     const int cobase = cot * BN;

@@ -419,11 +419,14 @@ static inline int conv_bn(int Cout) { return Cout <= 32 ? 32 : 128; }
 ConvTile conv_tile(const adk_op& op)
 {
     if (conv_bn(op.Cout) == 32) return {32, 128, false};
-    // short levels: too few (co, pos) tiles to fill 256 CUs and a serial K loop of up to 400 phases ->
-    // small tiles whose K range is split over the block's 4 waves (conv_ksplit.hip)
+    // Short levels: too few 128-row tiles to fill 256 CUs, serial K loop -> small tiles whose K range is split
+    // over the block's 4 waves (conv_ksplit.hip).  Measured on MI355X at B=16, C=512 (us, k=5): L=64 ks32x64 10.7
+    // vs pipelined 128x64 16.3; L=128 ks64x64 14.6 vs 17.0; L=256 pipelined 128x64 19.3 vs ks64x64 26.1 (the
+    // k-split kernel's direct operand loads saturate the L1 at ~470 TF/s); 1x1: L=128 pipelined 11.3 vs 13.8.
     if (op.L <= 32) return {32, 32, true};
     if (op.L <= 64) return {32, 64, true};
-    if (op.L <= 256) return {64, 64, true};
+    if (op.L <= 128 && op.taps != 1) return {64, 64, true};
+    if (op.L <= 256) return {128, 64, false};
     // wide tile (W amortised over 256 positions) from L = 2048 up.  The choice depends on L only, never on B:
     // the tile shape fixes the order in which GroupNorm partials are summed, and a sample's result must not
     // depend on how many other samples share its launch (batch sharding across GPUs stays bit-exact).
@@ -446,6 +449,7 @@ static int launch_tiles(const adk_op& op, hipStream_t st)
     const ConvTile t = conv_tile(op);
     if (t.bn == 32) return launch_variant<T, TO, TAPS, 1, 4, 1, 1>(op, st);
     if (t.bm == 256) return launch_variant<T, TO, TAPS, 2, 2, 2, 4>(op, st);
+    if (t.bm == 64) return launch_variant<T, TO, TAPS, 2, 2, 2, 1>(op, st);
     return launch_variant<T, TO, TAPS, 2, 2, 2, 2>(op, st);
 }
 

@@ -58,7 +58,10 @@ CONV_CASES = [
     (1, 16, 32, 64, 5, True, True),        # one channel chunk: three waves contribute zeros
     (3, 40, 160, 96, 1, False, True),      # 5 chunks (not a multiple of 4 waves), ragged 64-position tile
     (2, 128, 1024, 512, 5, True, False),   # concat input (32 chunks), 64x64 tiles
-    (2, 250, 96, 1536, 1, True, False),    # qkv projection shape, ragged last tile
+    (2, 250, 96, 1536, 1, True, False),    # qkv projection shape, ragged last tile (pipelined 128x64 tile)
+    (2, 100, 64, 128, 1, True, True),      # 1x1 at 64 < L <= 128: pipelined, where k=5 uses the k-split kernel
+    (2, 100, 64, 128, 5, True, True),
+    (3, 200, 128, 256, 5, True, False),    # L <= 256: pipelined 128x64 tile, ragged
 ]
 
 
@@ -93,6 +96,7 @@ def test_conv1d(env, dt, case):
     yd = torch.full((planes_out, B, L + 2 * P, cb), 7.0, dtype=dtype, device=dev)   # poison incl. halo
     op = _lib.AdkOp()
     op.kind, op.dtype, op.L, op.Cout, op.CoutPad, op.Cin, op.B = _lib.OP_CONV, adk, L, Cout, cout_pad, cin_alloc, B
+    op.taps = taps
     npart = lib.adk_partials_count(C.byref(op))
     part = torch.zeros(B, npart, 2, device=dev)
     rc = lib.adk_conv1d(adk, 0, B, L, P, cin_alloc, Cout, cout_pad, taps, xd.data_ptr(), wd.data_ptr(),

@@ -35,6 +35,7 @@ def main():
     y = torch.empty((a.cout + cb - 1) // cb, a.B, a.L + 2 * P, cb, dtype=dtype, device=dev)
     op = _lib.AdkOp()
     op.kind, op.dtype, op.L, op.Cout, op.CoutPad, op.Cin, op.B = _lib.OP_CONV, adk, a.L, a.cout, cp, a.cin, a.B
+    op.taps = a.taps
     part = torch.zeros(a.B, lib.adk_partials_count(C.byref(op)), 2, device=dev)
     st = torch.cuda.current_stream()
 

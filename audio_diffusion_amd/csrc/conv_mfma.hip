@@ -86,7 +86,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
         const int per = a.P * 4;
         const uint4 z = make_uint4(0, 0, 0, 0);
         unsigned char* yb = reinterpret_cast<unsigned char*>(a.y);
-        for (int p = tid; p < nplanes * per; p += 256) {
+        for (int p = tid; p < nplanes * per; p += (int)blockDim.x) {
             const int pl = plane0 + p / per, rem = p % per, row = rem >> 2, q = rem & 3;
             const long long mh = (long long)b * a.Lp + row;
             if (t == 0) *reinterpret_cast<uint4*>(yb + ((long long)pl * a.M + mh) * 64 + q * 16) = z;
@@ -233,16 +233,17 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <typename T, typename TO, int TAPS, int WCO, int WPOS, int TCO, int TPOS>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a)
+__global__ __launch_bounds__(WCO * WPOS * 64, 2) void conv_mfma_kernel(const ConvArgs a)
 {
     constexpr int BN = WCO * TCO * 32, BM = WPOS * TPOS * 32;
-    static_assert(WCO * WPOS == 4 && BN % 64 == 0, "pipelined variant: 4 waves, co tile a multiple of 64");
+    constexpr int NW = WCO * WPOS;               // waves per block: 4 (two blocks per CU) or 8 (one block per CU)
+    static_assert((NW == 4 || NW == 8) && BN % (16 * NW) == 0, "pipelined variant: 4 or 8 waves");
     constexpr int K = TAPS >= 3 ? 4 : 2;         // unit g+K is issued during phase g
     constexpr int RW = K + 1, RX = TAPS == 1 ? K + 1 : 2;
     constexpr int XROWS = BM + TAPS - 1;
-    constexpr int XI = (XROWS + 63) / 64;        // X LDS-DMA instructions per wave (uniform; tile padded)
-    constexpr int WI = BN / 64;                  // W LDS-DMA instructions per wave per unit
-    constexpr int XBYTES = XI * 4096, WBYTES = BN * 64;
+    constexpr int XI = (XROWS + 16 * NW - 1) / (16 * NW);    // X LDS-DMA instructions per wave (uniform; tile padded)
+    constexpr int WI = BN / (16 * NW);                        // W LDS-DMA instructions per wave per unit
+    constexpr int XBYTES = XI * NW * 1024, WBYTES = BN * 64;
     typedef typename Mma<T>::Frag Frag;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -273,14 +274,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a)
     unsigned xsrc[XI], wsrc[WI];
 #pragma unroll
     for (int j = 0; j < XI; ++j) {
-        const int row = (j * 4 + wave) * 16 + srow;
+        const int row = (j * NW + wave) * 16 + srow;
         long long m = mrow0 + row;
         m = m < 0 ? 0 : (m >= a.M ? a.M - 1 : m);
         xsrc[j] = (unsigned)(m * 64 + ((sslot ^ ((row >> 2) & 3)) << 4));
     }
 #pragma unroll
     for (int j = 0; j < WI; ++j) {
-        const int row = (j * 4 + wave) * 16 + srow;          // co_local
+        const int row = (j * NW + wave) * 16 + srow;         // co_local
         wsrc[j] = (unsigned)((cobase + row) * 64 + ((sslot ^ ((row >> 2) & 3)) << 4));
     }
 
@@ -290,12 +291,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a)
             const unsigned char* xb = xg + kc * xplane;
             unsigned char* dst = xs + (kc % RX) * XBYTES + wave * 1024;
 #pragma unroll
-            for (int j = 0; j < XI; ++j) glds16(xb + xsrc[j], dst + j * 4096);
+            for (int j = 0; j < XI; ++j) glds16(xb + xsrc[j], dst + j * (NW * 1024));
         }
         const unsigned char* wb = wg + kc * wchunk + (long long)tap * a.CoutPad * 64;
         unsigned char* dst = ws + (u % RW) * WBYTES + wave * 1024;
 #pragma unroll
-        for (int j = 0; j < WI; ++j) glds16(wb + wsrc[j], dst + j * 4096);
+        for (int j = 0; j < WI; ++j) glds16(wb + wsrc[j], dst + j * (NW * 1024));
     };
 
     f32x16 acc[TCO][TPOS];
@@ -383,8 +384,9 @@ static int launch_variant(const adk_op& op, hipStream_t st)
     conv_fill_args(op, BN, BM, a);
     if constexpr (BN >= 128) {
         constexpr int K = TAPS >= 3 ? 4 : 2;
-        constexpr int XI = (BM + TAPS - 1 + 63) / 64;
-        const size_t lds = (size_t)(TAPS == 1 ? K + 1 : 2) * XI * 4096 + (size_t)(K + 1) * BN * 64;
+        constexpr int NW = WCO * WPOS;
+        constexpr int XI = (BM + TAPS - 1 + 16 * NW - 1) / (16 * NW);
+        const size_t lds = (size_t)(TAPS == 1 ? K + 1 : 2) * XI * NW * 1024 + (size_t)(K + 1) * BN * 64;
         static bool attr_set = false;             // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel
         if (!attr_set) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, TO, TAPS, WCO, WPOS, TCO, TPOS>),
@@ -392,7 +394,7 @@ static int launch_variant(const adk_op& op, hipStream_t st)
                 return ADK_ELAUNCH;
             attr_set = true;
         }
-        hipLaunchKernelGGL((conv_mfma_kernel<T, TO, TAPS, WCO, WPOS, TCO, TPOS>), dim3(a.nblk), dim3(256), lds, st, a);
+        hipLaunchKernelGGL((conv_mfma_kernel<T, TO, TAPS, WCO, WPOS, TCO, TPOS>), dim3(a.nblk), dim3(NW * 64), lds, st, a);
     } else {
         const size_t lds = (size_t)((BM + TAPS - 1 + 15) / 16) * 1024 + (size_t)TAPS * BN * 64;
         hipLaunchKernelGGL((conv_mfma_simple_kernel<T, TO, TAPS, WCO, WPOS, TCO, TPOS>), dim3(a.nblk), dim3(256), lds, st, a);
@@ -463,7 +465,8 @@ static int launch_taps(const adk_op& op, hipStream_t st)
 
 int launch_conv(const adk_op& op, hipStream_t st)
 {
-    if (conv_tile(op).ksplit) return launch_conv_ksplit(op, st);
+    const ConvTile ct = conv_tile(op);
+    if (ct.ksplit) return launch_conv_ksplit(op, st);
     if (op.dtype == ADK_F32) return launch_taps<float, float>(op, st);
     if (op.flags & ADK_FLAG_OUT_F32) return launch_taps<bf16_t, float>(op, st);
     return launch_taps<bf16_t, bf16_t>(op, st);

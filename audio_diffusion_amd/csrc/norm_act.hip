@@ -100,7 +100,9 @@ __global__ __launch_bounds__(256) void gn_kernel(const GnArgs a)
     }
 }
 
-static inline int gn_rb(int L) { return L >= 1024 ? 1024 : ((L + 63) / 64) * 64; }
+// rows per block: 64 KiB of a plane at the long levels, smaller below so that the mid levels still launch >= 1024
+// blocks (one block per CU is latency-bound: 1.8 TB/s at L = 1024 with 1024-row blocks)
+static inline int gn_rb(int L) { return L >= 8192 ? 1024 : (L >= 256 ? 256 : ((L + 63) / 64) * 64); }
 
 int gn_partials_count(int dtype, int C, int L) {
     const int CB = dtype == ADK_F32 ? 16 : 32;

@@ -38,46 +38,71 @@ __global__ __launch_bounds__(256) void fir_kernel(const FirArgs a)
                               (((long long)plane * Mi + (long long)b * Lpi + a.P) * 64) + q * 16;
     unsigned char* yb = reinterpret_cast<unsigned char*>(a.y) + (((long long)plane * Mo + (long long)b * Lpo) * 64) + q * 16;
 
+    // Each thread produces RUN consecutive output rows (down) / output row pairs (up) from a sliding window of
+    // input rows, so an input row is fetched ~1.4 times instead of K/2 (down) or K/2+1 (up) times.
+    constexpr int RUN = 4;
     if (!UP) {
         const int lbeg = rb * a.RB, lend = lbeg + a.RB < a.Lo ? lbeg + a.RB : a.Lo;
-        for (int lo = lbeg + r0; lo < lend; lo += 64) {
-            float acc[NV];
+        for (int lo = lbeg + r0 * RUN; lo < lend; lo += 64 * RUN) {
+            float acc[RUN][NV];
 #pragma unroll
-            for (int e = 0; e < NV; ++e) acc[e] = 0.f;
+            for (int u = 0; u < RUN; ++u)
 #pragma unroll
-            for (int j = 0; j < K; ++j) {
-                const int li = reflect(2 * lo + j - (K / 2 - 1), a.L);
+                for (int e = 0; e < NV; ++e) acc[u][e] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2 * (RUN - 1) + K; ++i) {          // input row 2*lo - (K/2-1) + i feeds output u with tap i - 2u
+                const int li = reflect(2 * lo + i - (K / 2 - 1), a.L);
                 float f[NV];
                 piece_to_float(*reinterpret_cast<const uint4*>(xb + (long long)li * 64), f, T());
 #pragma unroll
-                for (int e = 0; e < NV; ++e) acc[e] += k[j] * f[e];
+                for (int u = 0; u < RUN; ++u) {
+                    const int j = i - 2 * u;
+                    if (j >= 0 && j < K) {
+#pragma unroll
+                        for (int e = 0; e < NV; ++e) acc[u][e] += k[j] * f[e];
+                    }
+                }
             }
-            *reinterpret_cast<uint4*>(yb + (long long)(a.P + lo) * 64) = float_to_piece(acc, T());
+#pragma unroll
+            for (int u = 0; u < RUN; ++u)
+                if (lo + u < lend) *reinterpret_cast<uint4*>(yb + (long long)(a.P + lo + u) * 64) = float_to_piece(acc[u], T());
         }
     } else {
         // a.RB counts INPUT rows m here; each produces output rows 2m, 2m+1
         const int mbeg = rb * a.RB, mend = mbeg + a.RB < a.L ? mbeg + a.RB : a.L;
-        for (int m = mbeg + r0; m < mend; m += 64) {
-            float ev[NV], od[NV];
+        for (int m = mbeg + r0 * RUN; m < mend; m += 64 * RUN) {
+            float ev[RUN][NV], od[RUN][NV];
 #pragma unroll
-            for (int e = 0; e < NV; ++e) { ev[e] = 0.f; od[e] = 0.f; }
+            for (int u = 0; u < RUN; ++u)
 #pragma unroll
-            for (int d = -(K / 4); d <= K / 2 - K / 4; ++d) {
+                for (int e = 0; e < NV; ++e) { ev[u][e] = 0.f; od[u][e] = 0.f; }
+#pragma unroll
+            for (int i = 0; i < RUN + K / 2; ++i) {                 // input row m - K/4 + i feeds pair u with offset d = i - K/4 - u
                 float f[NV];
-                piece_to_float(*reinterpret_cast<const uint4*>(xb + (long long)reflect(m + d, a.L) * 64), f, T());
-                const int je = K - 1 - 2 * (d + K / 4);     // odd tap feeding y[2m]
-                const int jo = K - 2 * (d + K / 4);         // even tap feeding y[2m+1]
-                if (je >= 0 && je < K) {
+                piece_to_float(*reinterpret_cast<const uint4*>(xb + (long long)reflect(m - K / 4 + i, a.L) * 64), f, T());
 #pragma unroll
-                    for (int e = 0; e < NV; ++e) ev[e] += k[je] * f[e];
-                }
-                if (jo >= 0 && jo < K) {
+                for (int u = 0; u < RUN; ++u) {
+                    const int d = i - K / 4 - u;
+                    if (d >= -(K / 4) && d <= K / 2 - K / 4) {
+                        const int je = K - 1 - 2 * (d + K / 4);     // odd tap feeding y[2m]
+                        const int jo = K - 2 * (d + K / 4);         // even tap feeding y[2m+1]
+                        if (je >= 0 && je < K) {
 #pragma unroll
-                    for (int e = 0; e < NV; ++e) od[e] += k[jo] * f[e];
+                            for (int e = 0; e < NV; ++e) ev[u][e] += k[je] * f[e];
+                        }
+                        if (jo >= 0 && jo < K) {
+#pragma unroll
+                            for (int e = 0; e < NV; ++e) od[u][e] += k[jo] * f[e];
+                        }
+                    }
                 }
             }
-            *reinterpret_cast<uint4*>(yb + (long long)(a.P + 2 * m) * 64) = float_to_piece(ev, T());
-            *reinterpret_cast<uint4*>(yb + (long long)(a.P + 2 * m + 1) * 64) = float_to_piece(od, T());
+#pragma unroll
+            for (int u = 0; u < RUN; ++u)
+                if (m + u < mend) {
+                    *reinterpret_cast<uint4*>(yb + (long long)(a.P + 2 * (m + u)) * 64) = float_to_piece(ev[u], T());
+                    *reinterpret_cast<uint4*>(yb + (long long)(a.P + 2 * (m + u) + 1) * 64) = float_to_piece(od[u], T());
+                }
         }
     }
     if (rb == 0 || rb == a.nrb - 1) {

@@ -19,6 +19,7 @@ int launch_pack_input(const adk_op& op, hipStream_t st);
 int launch_unpack_output(const adk_op& op, hipStream_t st);
 int launch_ddim_update(const adk_op& op, hipStream_t st);
 int launch_step_advance(const adk_op& op, hipStream_t st);
+int launch_audio_to_int16(const adk_op& op, hipStream_t st);
 
 static thread_local char g_err[512] = "";
 
@@ -119,6 +120,10 @@ static int validate(const adk_op& o)
     case ADK_OP_STEP_ADVANCE:
         REQUIRE(o.y, "step_advance: null counter");
         return ADK_OK;
+    case ADK_OP_AUDIO_TO_INT16:
+        REQUIRE(o.B >= 1 && o.Cin >= 1 && o.L >= 1 && o.x && o.y, "audio_to_int16: bad arguments");
+        REQUIRE((long long)o.B * o.Cin <= 65535, "audio_to_int16: B*C=%lld exceeds 65535", (long long)o.B * o.Cin);
+        return ADK_OK;
     default:
         return fail(ADK_EINVAL, "unknown op kind %d", o.kind);
     }
@@ -139,6 +144,7 @@ static int dispatch(const adk_op& o, hipStream_t st)
     case ADK_OP_PQMF_SYNTHESIS: return launch_pqmf(o, st, true);
     case ADK_OP_DDIM_UPDATE: return launch_ddim_update(o, st);
     case ADK_OP_STEP_ADVANCE: return launch_step_advance(o, st);
+    case ADK_OP_AUDIO_TO_INT16: return launch_audio_to_int16(o, st);
     }
     return ADK_EINVAL;
 }
@@ -294,6 +300,13 @@ int adk_ddim_update(uint32_t flags, int64_t n, float* x, const float* v, const f
     adk_op o = zero_op(ADK_OP_DDIM_UPDATE, ADK_F32);
     o.flags = flags; o.i0 = (int32_t)(n & 0x7fffffff); o.i1 = (int32_t)(n >> 31);
     o.y = x; o.x = v; o.residual = noise; o.aux1 = pred; o.aux0 = coef; o.bias = reinterpret_cast<const float*>(step);
+    return adk_run_plan(&o, 1, stream);
+}
+
+int adk_audio_to_int16(int B, int C, int T, const float* x, int16_t* y, void* stream)
+{
+    adk_op o = zero_op(ADK_OP_AUDIO_TO_INT16, ADK_F32);
+    o.B = B; o.Cin = C; o.L = T; o.x = x; o.y = y;
     return adk_run_plan(&o, 1, stream);
 }
 

@@ -164,3 +164,34 @@ int launch_step_advance(const adk_op& op, hipStream_t st)
     hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<int32_t*>(op.y));
     return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
 }
+
+// ---- demo output stage: rearrange(b d n -> d (b n)).clamp(-1, 1).mul(32767).to(int16) ---------------------
+// (reference train_uncond.py:182-187).  x f32 [B, C, T] -> y int16 [C, B*T]; truncation toward zero like torch.
+struct PcmArgs { const float* x; short* y; int B, C, T; };
+
+__global__ __launch_bounds__(256) void audio_to_int16_kernel(const PcmArgs a)
+{
+    const int bc = blockIdx.y, b = bc / a.C, c = bc % a.C;
+    const float* xin = a.x + (long long)bc * a.T;
+    short* yout = a.y + ((long long)c * a.B + b) * a.T;
+    const int n4 = ((reinterpret_cast<uintptr_t>(xin) & 15) == 0 && (reinterpret_cast<uintptr_t>(yout) & 7) == 0) ? a.T / 4 : 0;
+    auto cv = [](float v) -> int { v = v < -1.f ? -1.f : (v > 1.f ? 1.f : v); return (int)(v * 32767.f); };
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(xin)[i];
+        const unsigned lo = (unsigned)(cv(v.x) & 0xffff) | ((unsigned)cv(v.y) << 16);
+        const unsigned hi = (unsigned)(cv(v.z) & 0xffff) | ((unsigned)cv(v.w) << 16);
+        reinterpret_cast<uint2*>(yout)[i] = make_uint2(lo, hi);
+    }
+    for (int i = n4 * 4 + blockIdx.x * 256 + threadIdx.x; i < a.T; i += gridDim.x * 256) yout[i] = (short)cv(xin[i]);
+}
+
+int launch_audio_to_int16(const adk_op& op, hipStream_t st)
+{
+    PcmArgs a;
+    a.x = reinterpret_cast<const float*>(op.x); a.y = reinterpret_cast<short*>(op.y);
+    a.B = op.B; a.C = op.Cin; a.T = op.L;
+    int bx = (op.L / 4 + 255) / 256;
+    bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
+    hipLaunchKernelGGL(audio_to_int16_kernel, dim3(bx, op.B * op.Cin), dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
+}

@@ -26,10 +26,20 @@ def alpha_sigma_to_t(alpha, sigma):
     return torch.atan2(sigma, alpha) / math.pi * 2
 
 
-def step_coefficients(steps, eta):
+def get_crash_schedule(t):
+    """Timestep warp used by the training demos (reference train_uncond.py:35-38)."""
+    sigma = torch.sin(t * math.pi / 2) ** 2
+    alpha = (1 - sigma ** 2) ** 0.5
+    return alpha_sigma_to_t(alpha, sigma)
+
+
+def step_coefficients(steps, eta, warp=None):
     """Host table [steps, 8] = (t, alpha, sigma, alpha_next, adjusted_sigma, ddim_sigma, is_last, 0),
-    computed with the reference's CPU fp32 expressions (sampling.py:22-24, 42-44)."""
+    computed with the reference's CPU fp32 expressions (sampling.py:22-24, 42-44).  ``warp`` maps the linear
+    timesteps first (train_uncond.py:51-55 applies get_crash_schedule there)."""
     t = torch.linspace(1, 0, steps + 1)[:-1]
+    if warp is not None:
+        t = warp(t)
     alphas, sigmas = get_alphas_sigmas(t)
     tab = torch.zeros(steps, 8, dtype=torch.float32)
     tab[:, 0], tab[:, 1], tab[:, 2] = t, alphas, sigmas
@@ -107,11 +117,46 @@ def sample(model, x, steps, eta, **extra_args):
 
     Returns the LAST step's ``pred``; ``x`` is not modified; ``randn_like`` is drawn only when ``eta`` is
     truthy; ``extra_args`` are forwarded to ``model`` (generic path)."""
+    return _sample(model, x, steps, eta, None, extra_args)
+
+
+@torch.no_grad()
+def sample_crash(model, x, steps, eta):
+    """The training demos' sampler: same loop on the crash-warped timesteps (reference train_uncond.py:45-86)."""
+    return _sample(model, x, steps, eta, get_crash_schedule, {})
+
+
+@torch.no_grad()
+def sample_diffae(model, signal, steps, eta):
+    """Diffusion-autoencoder DDIM (reference diffusion/inference.py:14-57): ``z_sem = model.encode(signal)``,
+    start from fresh noise, denoise with ``model.decode(x, t, z_sem)``.  ``model`` is any object with those two
+    methods; the per-step update runs in the fused kernel."""
+    z_sem = model.encode(signal)
+    x = torch.randn_like(signal)
+    return _sample(lambda xx, tt: model.decode(xx, tt, z_sem), x, steps, eta, None, {})
+
+
+@torch.no_grad()
+def audio_to_int16(fakes):
+    """``rearrange(fakes, 'b d n -> d (b n)').clamp(-1, 1).mul(32767).to(torch.int16)`` in one kernel — the output
+    stage every caller of ``sample`` applies before saving (reference train_uncond.py:182-187)."""
+    if not fakes.is_cuda or fakes.dim() != 3:
+        raise RuntimeError("audio_to_int16 expects a [B, C, T] tensor on a ROCm device")
+    lib = _lib.load()
+    x = fakes.detach().to(torch.float32).contiguous()
+    B, C, T = x.shape
+    y = torch.empty(C, B * T, dtype=torch.int16, device=x.device)
+    _lib.check(lib.adk_audio_to_int16(B, C, T, x.data_ptr(), y.data_ptr(),
+                                      torch.cuda.current_stream(x.device).cuda_stream), "adk_audio_to_int16")
+    return y
+
+
+def _sample(model, x, steps, eta, warp, extra_args):
     if not x.is_cuda:
         raise RuntimeError("sample(): MI355X build runs on ROCm devices only; there is no CPU path")
     if steps < 1:
         raise ValueError("steps must be >= 1")
-    coef = step_coefficients(steps, eta)
+    coef = step_coefficients(steps, eta, warp)
     x = x.detach().to(torch.float32).contiguous()
     fused = isinstance(model, DiffusionAttnUnet1D) and not extra_args
     if fused and not eta:

@@ -49,7 +49,8 @@ enum {
     ADK_OP_PQMF_ANALYSIS = 9, /* CachedPQMF.forward: diffusion/pqmf.py:271-283                       */
     ADK_OP_PQMF_SYNTHESIS = 10, /* CachedPQMF.inverse: diffusion/pqmf.py:285-302                     */
     ADK_OP_DDIM_UPDATE = 11,  /* per-step v-DDIM update: diffusion/sampling.py:34-52                 */
-    ADK_OP_STEP_ADVANCE = 12  /* device-side step counter ++ (lets one hipGraph replay every step)   */
+    ADK_OP_STEP_ADVANCE = 12, /* device-side step counter ++ (lets one hipGraph replay every step)   */
+    ADK_OP_AUDIO_TO_INT16 = 13 /* demo output stage: train_uncond.py:182-187                          */
 };
 
 /* flags */
@@ -158,6 +159,11 @@ int adk_ddim_update(uint32_t flags, int64_t n, float *x, const float *v, const f
                     const float *coef, const int32_t *step, void *stream);
 
 int adk_step_advance(int32_t *step, void *stream);
+
+/* Replaces the output stage every caller of sample() applies (train_uncond.py:182-187, generate.py):
+ *   rearrange(fakes, 'b d n -> d (b n)').clamp(-1, 1).mul(32767).to(torch.int16)
+ * x f32 [B, C, T] -> y int16 [C, B*T] (truncation toward zero, like torch's float -> int16 cast). */
+int adk_audio_to_int16(int B, int C, int T, const float *x, int16_t *y, void *stream);
 
 #ifdef __cplusplus
 }

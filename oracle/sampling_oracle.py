@@ -10,9 +10,21 @@ import math
 import torch
 
 
-def schedule(steps):
-    """sampling.py:22-24: t = linspace(1,0,steps+1)[:-1]; alpha=cos(t*pi/2); sigma=sin(t*pi/2)."""
+def crash_schedule(t):
+    """train_uncond.py:35-38 (get_crash_schedule): sigma = sin(t pi/2)^2, alpha = sqrt(1 - sigma^2), back to t.
+    That script cannot be imported here (prefigure / wandb / aeiou are absent), so this three-line warp is pinned
+    only by restating its formula: parity unpinned for the warp itself; the loop around it is the pinned one."""
+    sigma = torch.sin(t * math.pi / 2) ** 2
+    alpha = (1 - sigma ** 2) ** 0.5
+    return alpha_sigma_to_t(alpha, sigma)
+
+
+def schedule(steps, crash=False):
+    """sampling.py:22-24: t = linspace(1,0,steps+1)[:-1]; alpha=cos(t*pi/2); sigma=sin(t*pi/2).
+    crash=True applies train_uncond.py:53 (t = get_crash_schedule(t)) first."""
     t = torch.linspace(1, 0, steps + 1)[:-1]
+    if crash:
+        t = crash_schedule(t)
     return t, torch.cos(t * math.pi / 2), torch.sin(t * math.pi / 2)
 
 
@@ -22,10 +34,10 @@ def alpha_sigma_to_t(alpha, sigma):
 
 
 @torch.no_grad()
-def ddim_sample(model, x, steps, eta, trace=None, **extra):
-    """sampling.py:16-55.  ``trace`` (optional list) receives each step's v."""
+def ddim_sample(model, x, steps, eta, trace=None, crash=False, **extra):
+    """sampling.py:16-55.  ``trace`` (optional list) receives each step's v.  crash=True: train_uncond.py:45-86."""
     ones = x.new_ones([x.shape[0]])
-    t, alphas, sigmas = schedule(steps)
+    t, alphas, sigmas = schedule(steps, crash)
     pred = None
     for i in range(steps):
         v = model(x, ones * t[i], **extra).float()

@@ -124,3 +124,55 @@ def test_full_model_first_call_and_10_steps():
     m.compute_dtype = torch.bfloat16
     v0b = m(x, torch.ones(1, device=dev))
     assert rel_err(v0b, ref_v0) <= 2e-2
+
+
+def test_crash_schedule_sampler_and_int16_output_stage():
+    """the training demos' sampler (train_uncond.py:45-86: crash-warped timesteps) against the oracle
+    loop on the same warp, and the int16 output stage (train_uncond.py:182-187) bit-exact against torch."""
+    import audio_diffusion_amd as A
+    from oracle import unet_oracle as U, sampling_oracle as S
+    dev = torch.device("cuda:0")
+    z = load_npz("tiny_d3.npz")
+    m = build(z, dev)
+    m.compute_dtype = torch.float32
+    cfg = json.loads(bytes(z["cfg"]).decode())
+    ref_model = U.make_model_fn(sub_sd(z, "sd/"), U.make_config(**cfg))
+    x = torch.from_numpy(z["x"])
+    want = S.ddim_sample(ref_model, x, 6, 0, crash=True)
+    got = A.sample_crash(m, x.to(dev), 6, 0)
+    assert rel_err(got, want) <= 1e-4 and snr_db(got, want) >= 60.0
+    assert not torch.allclose(got.cpu(), S.ddim_sample(ref_model, x, 6, 0), atol=1e-3)      # the warp matters
+
+    fakes = torch.randn(3, 2, 1001, device=dev) * 0.8                                   # odd length: scalar tail
+    fakes[0, 0, :4] = torch.tensor([1.5, -1.5, 1.0, -1.0], device=dev)
+    pcm = A.audio_to_int16(fakes)
+    ref = fakes.cpu().permute(1, 0, 2).reshape(2, -1).clamp(-1, 1).mul(32767).to(torch.int16)
+    assert pcm.dtype == torch.int16 and torch.equal(pcm.cpu(), ref)
+    big = torch.randn(4, 2, 65536, device=dev)
+    assert torch.equal(A.audio_to_int16(big).cpu(), big.cpu().permute(1, 0, 2).reshape(2, -1).clamp(-1, 1).mul(32767).to(torch.int16))
+
+
+def test_diffae_sampler_variant():
+    """diffusion/inference.py:14-57: encode once, start from fresh noise, decode(x, t, z_sem) per step."""
+    import audio_diffusion_amd as A
+    from oracle import sampling_oracle as S
+    dev = torch.device("cuda:0")
+    z = load_npz("tiny_d3.npz")
+    m = build(z, dev)
+    m.compute_dtype = torch.float32
+
+    class DiffAE:
+        def encode(self, signal):
+            return signal.mean(dim=2, keepdim=True)
+
+        def decode(self, x, t, z_sem):
+            return m(x + 0.1 * z_sem, t)
+
+    sig = torch.from_numpy(z["x"]).to(dev)
+    torch.manual_seed(11)
+    got = A.sample_diffae(DiffAE(), sig, 4, 0)
+    torch.manual_seed(11)
+    x0 = torch.randn_like(sig)
+    zs = sig.mean(dim=2, keepdim=True)
+    want = A.sample(lambda xx, tt: m(xx + 0.1 * zs, tt), x0, 4, 0)
+    assert torch.equal(got, want) and torch.isfinite(got).all()

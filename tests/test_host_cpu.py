@@ -151,3 +151,14 @@ def test_pqmf_design_matches_reference_tables(golden_pqmf):
         for key, ref in (("hk", "hk"), ("h", "h"), ("forward_conv.weight", "fw"), ("inverse_conv.weight", "iw")):
             assert sd[key].shape == tuple(z[f"{tag}/{ref}"].shape)
             assert float((sd[key] - torch.from_numpy(z[f"{tag}/{ref}"])).abs().max()) <= 1e-6
+
+
+def test_crash_schedule_table_matches_oracle():
+    """step_coefficients(warp=get_crash_schedule) == the oracle's crash-warped schedule, bit for bit."""
+    import audio_diffusion_amd as A
+    from oracle import sampling_oracle as S
+    for steps in (5, 50):
+        tab = A.step_coefficients(steps, 0.0, warp=A.get_crash_schedule)
+        t, al, si = S.schedule(steps, crash=True)
+        assert torch.equal(tab[:, 0], t) and torch.equal(tab[:, 1], al) and torch.equal(tab[:, 2], si)
+        assert float(tab[0, 0]) == 1.0 and bool((tab[1:, 0] < tab[:-1, 0]).all())

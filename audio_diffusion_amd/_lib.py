@@ -38,7 +38,7 @@ class AdkOp(C.Structure):
 EXPORTS = [
     "adk_version", "adk_last_error", "adk_run_plan", "adk_validate_plan", "adk_partials_count", "adk_conv_postile", "adk_conv_cotile_used", "adk_conv_cotile",
     "adk_conv1d", "adk_gn_apply", "adk_gn_stats", "adk_fir_down2", "adk_fir_up2", "adk_attn1d",
-    "adk_pack_input", "adk_unpack_output", "adk_pqmf_analysis", "adk_pqmf_synthesis",
+    "adk_pack_input", "adk_pack_input_cond", "adk_unpack_output", "adk_pqmf_analysis", "adk_pqmf_synthesis",
     "adk_ddim_update", "adk_step_advance", "adk_audio_to_int16",
 ]
 
@@ -77,6 +77,7 @@ def load():
     lib.adk_fir_up2.argtypes = [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.adk_attn1d.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp]
     lib.adk_pack_input.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp]
+    lib.adk_pack_input_cond.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp, vp]
     lib.adk_unpack_output.argtypes = [i32, i32, i32, i32, vp, vp, vp]
     lib.adk_pqmf_analysis.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.adk_pqmf_synthesis.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, vp]

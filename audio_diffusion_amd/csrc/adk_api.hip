@@ -95,6 +95,8 @@ static int validate(const adk_op& o)
     case ADK_OP_PACK_INPUT:
         if ((rc = check_geo(o, "pack_input"))) return rc;
         REQUIRE(o.Cin >= 1 && o.x && o.w && o.y && o.aux0, "pack_input: null tensor");
+        REQUIRE(!o.residual || (o.Cout >= 1 && o.i1 >= 1), "pack_input: cond needs Cc >= 1 and Lc >= 1 (got %d, %d)", o.Cout, o.i1);
+        REQUIRE(!o.gamma || o.residual, "pack_input: noise-aug levels without a cond tensor");
         return ADK_OK;
     case ADK_OP_UNPACK_OUTPUT:
         if ((rc = check_geo(o, "unpack_output"))) return rc;
@@ -270,6 +272,18 @@ int adk_pack_input(int dtype, int B, int L, int P, int Cx, const float* x, const
     adk_op o = zero_op(ADK_OP_PACK_INPUT, dtype);
     o.B = B; o.L = L; o.P = P; o.Cin = Cx; o.x = x; o.aux0 = t; o.bias = reinterpret_cast<const float*>(step);
     o.i0 = t_stride; o.w = fw; o.y = y;
+    return adk_run_plan(&o, 1, stream);
+}
+
+int adk_pack_input_cond(int dtype, int B, int L, int P, int Cx, const float* x, const float* t,
+                        const int32_t* step, int t_stride, const float* fw,
+                        const float* cond, int Cc, int Lc, const float* aug_level, const float* aug_noise,
+                        void* y, void* stream)
+{
+    adk_op o = zero_op(ADK_OP_PACK_INPUT, dtype);
+    o.B = B; o.L = L; o.P = P; o.Cin = Cx; o.x = x; o.aux0 = t; o.bias = reinterpret_cast<const float*>(step);
+    o.i0 = t_stride; o.w = fw; o.y = y;
+    o.residual = cond; o.Cout = Cc; o.i1 = Lc; o.gamma = aug_level; o.aux1 = const_cast<float*>(aug_noise);
     return adk_run_plan(&o, 1, stream);
 }
 

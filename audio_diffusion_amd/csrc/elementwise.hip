@@ -12,28 +12,53 @@
 
 struct PackArgs {
     const float* x; const float* t; const int32_t* step; const float* fw; void* y;
-    int B, L, P, Lp, Cx, nplanes, t_stride; long long M;
+    const float* aug; const float* cond;          // optional: noise-aug levels [B]; conditioning [B, Cc, Lc]
+    const float* noise;                            // optional: N(0,1) draw [B, Cc, L] added to cond scaled by aug[b]
+    int B, L, P, Lp, Cx, nplanes, t_stride, Cc, Lc; long long M;
+    float cscale;                                  // Lc / L, rounded to f32 like ATen's area_pixel_compute_scale
 };
 
+// Channel order of the network input (decoders/diffusion_decoder.py:146-171):
+//   [ x (Cx) | timestep embedding (16) | noise-aug level embedding (16, only with cond_noise_aug) | cond (Cc) ]
+// cond is resampled to L with F.interpolate(mode='linear', align_corners=False) semantics (:150-151):
+//   src = scale * (l + 0.5) - 0.5, clamped at 0; out = (1 - w) * in[i0] + w * in[min(i0 + 1, Lc - 1)].
 template <typename T>
 __global__ __launch_bounds__(256) void pack_input_kernel(const PackArgs a)
 {
     constexpr int NV = ElemTraits<T>::NV, CB = ElemTraits<T>::CB;
-    __shared__ float emb[16];
+    __shared__ float emb[32];
     const int plane = blockIdx.y, b = blockIdx.z;
-    if (threadIdx.x < 16) {
-        const float tv = a.step ? a.t[(long long)(*a.step) * a.t_stride] : a.t[b];
+    if (threadIdx.x < 32) {
+        const bool second = threadIdx.x >= 16;
+        float tv = 0.f;
+        if (!second) tv = a.step ? a.t[(long long)(*a.step) * a.t_stride] : a.t[b];
+        else if (a.aug) tv = a.aug[b];
         const int j = threadIdx.x & 7;
         // 2 * math.pi * input @ weight.T : ((2*pi) * t) * w, each product rounded to f32
         const float tp = 6.283185307179586f * tv;
         const float f = tp * a.fw[j];
-        emb[threadIdx.x] = threadIdx.x < 8 ? cosf(f) : sinf(f);
+        emb[threadIdx.x] = (threadIdx.x & 15) < 8 ? cosf(f) : sinf(f);
     }
     __syncthreads();
     const int r = blockIdx.x * 256 + threadIdx.x;          // row within the sample, halo included
     if (r >= a.Lp) return;
     const int l = r - a.P;
     const bool valid = l >= 0 && l < a.L;
+    const int nemb = a.aug ? 32 : 16, c_cond = a.Cx + nemb;
+    int i0 = 0, i1 = 0;
+    float w0 = 1.f, w1 = 0.f;
+    if (a.cond && valid) {
+        if (a.Lc == a.L) { i0 = i1 = l; }
+        else {
+            float src = a.cscale * ((float)l + 0.5f) - 0.5f;
+            src = src < 0.f ? 0.f : src;
+            i0 = (int)src;
+            i0 = i0 > a.Lc - 1 ? a.Lc - 1 : i0;
+            i1 = i0 < a.Lc - 1 ? i0 + 1 : i0;
+            w1 = src - (float)i0;
+            w0 = 1.f - w1;
+        }
+    }
     unsigned char* yrow = reinterpret_cast<unsigned char*>(a.y) + ((long long)plane * a.M + (long long)b * a.Lp + r) * 64;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -44,7 +69,12 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const PackArgs a)
             float v = 0.f;
             if (valid) {
                 if (c < a.Cx) v = a.x[((long long)b * a.Cx + c) * a.L + l];
-                else if (c < a.Cx + 16) v = emb[c - a.Cx];
+                else if (c < c_cond) v = emb[c - a.Cx];
+                else if (c < c_cond + a.Cc) {
+                    const float* cp = a.cond + ((long long)b * a.Cc + (c - c_cond)) * a.Lc;
+                    v = a.Lc == a.L ? cp[i0] : w0 * cp[i0] + w1 * cp[i1];
+                    if (a.noise) v = v + a.noise[((long long)b * a.Cc + (c - c_cond)) * a.L + l] * a.aug[b];   // :160
+                }
             }
             f[e] = v;
         }
@@ -57,9 +87,13 @@ int launch_pack_input(const adk_op& op, hipStream_t st)
     PackArgs a;
     a.x = reinterpret_cast<const float*>(op.x); a.t = reinterpret_cast<const float*>(op.aux0);
     a.step = reinterpret_cast<const int32_t*>(op.bias); a.fw = reinterpret_cast<const float*>(op.w); a.y = op.y;
+    a.aug = op.gamma; a.cond = reinterpret_cast<const float*>(op.residual);
+    a.noise = op.gamma ? reinterpret_cast<const float*>(op.aux1) : nullptr;
+    a.Cc = a.cond ? op.Cout : 0; a.Lc = a.cond ? op.i1 : 0;
+    a.cscale = a.cond ? (float)a.Lc / (float)op.L : 0.f;
     a.B = op.B; a.L = op.L; a.P = op.P; a.Lp = op.L + 2 * op.P; a.Cx = op.Cin; a.t_stride = op.i0;
     a.M = (long long)op.B * a.Lp;
-    const int Cp = (op.Cin + 16 + 31) / 32 * 32;
+    const int Cp = (op.Cin + (a.aug ? 32 : 16) + a.Cc + 31) / 32 * 32;
     const int CB = op.dtype == ADK_F32 ? 16 : 32;
     a.nplanes = Cp / CB;
     dim3 grid((a.Lp + 255) / 256, a.nplanes, op.B);

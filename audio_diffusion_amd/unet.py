@@ -71,9 +71,10 @@ class _ArenaPlanner:
 class _Plan:
     """Compiled forward for one (B, T, dtype).  ``ops`` is a ctypes array of adk_op."""
 
-    def __init__(self, model, B, T, dtype, device, t_table=None):
+    def __init__(self, model, B, T, dtype, device, t_table=None, cond_len=0):
         self.lib = _lib.load()
         self.model, self.B, self.T, self.device = model, B, T, device
+        self.cond_len = cond_len          # 0: no cond input; else length of the [B, cond_dim, cond_len] tensor
         self.dtype = dtype
         self.adk_dtype = _lib.ADK_F32 if dtype == torch.float32 else _lib.ADK_BF16
         self.CB = 16 if dtype == torch.float32 else 32
@@ -301,17 +302,26 @@ class _Plan:
             self._emit(_lib.OP_PQMF_ANALYSIS, {"x": ("input", 0), "w": ("abs", fwT.data_ptr()), "y": ("arena", ana.off)},
                        Cin=m.io_channels, L=self.T, i0=bands, taps=fwT.shape[0])
             x_ptrs = {"x": ("arena", ana.off)}
-        x0 = self.tensor(_ceil_to(cx + 16, 32), L0)
-        x0.C = cx + 16
+        # network input = [x | emb(t) | (emb(aug level)) | cond]  (reference diffusion_decoder.py:146-171)
+        has_cond = self.cond_len > 0
+        cin0 = cx + (32 if (has_cond and m.cond_noise_aug) else 16) + (m.cond_dim if has_cond else 0)
+        x0 = self.tensor(_ceil_to(cin0, 32), L0)
+        x0.C = cin0
         fw = self._padded_vec("timestep_embed.weight", m.timestep_embed.weight, 8)
         ptrs = dict(x_ptrs, w=("abs", fw), y=("arena", x0.off))
+        extra = {}
+        if has_cond:
+            ptrs["residual"] = ("cond", 0)
+            extra = dict(Cout=m.cond_dim, i1=self.cond_len)
+            if m.cond_noise_aug:
+                ptrs["gamma"], ptrs["aux1"] = ("aug", 0), ("noise", 0)
         if self.t_table is None:
             ptrs["aux0"] = ("t", 0)
-            self._emit(_lib.OP_PACK_INPUT, ptrs, L=L0, Cin=cx)
+            self._emit(_lib.OP_PACK_INPUT, ptrs, L=L0, Cin=cx, **extra)
         else:
             coef_ptr, step_ptr = self.t_table
             ptrs["aux0"], ptrs["bias"] = ("abs", coef_ptr), ("abs", step_ptr)
-            self._emit(_lib.OP_PACK_INPUT, ptrs, L=L0, Cin=cx, i0=8)
+            self._emit(_lib.OP_PACK_INPUT, ptrs, L=L0, Cin=cx, i0=8, **extra)
         if bands > 1:
             self.free(ana)
 
@@ -344,7 +354,7 @@ class _Plan:
         base = self.arena.data_ptr()
         n = len(self._ops)
         self.ops = (_lib.AdkOp * n)()
-        self._patch = {"input": [], "output": [], "t": []}
+        self._patch = {"input": [], "output": [], "t": [], "cond": [], "aug": [], "noise": []}
         for i, (op, ptrs) in enumerate(self._ops):
             for field, (kind, val) in ptrs.items():
                 if kind == "arena":
@@ -357,13 +367,11 @@ class _Plan:
         self.n_ops = n
         del self._ops
 
-    def bind(self, x_ptr, t_ptr, out_ptr):
-        for i, f in self._patch["input"]:
-            setattr(self.ops[i], f, x_ptr)
-        for i, f in self._patch["t"]:
-            setattr(self.ops[i], f, t_ptr)
-        for i, f in self._patch["output"]:
-            setattr(self.ops[i], f, out_ptr)
+    def bind(self, x_ptr, t_ptr, out_ptr, cond_ptr=0, aug_ptr=0, noise_ptr=0):
+        for kind, ptr in (("input", x_ptr), ("t", t_ptr), ("output", out_ptr), ("cond", cond_ptr), ("aug", aug_ptr),
+                          ("noise", noise_ptr)):
+            for i, f in self._patch[kind]:
+                setattr(self.ops[i], f, ptr)
 
     def run(self, stream_ptr):
         _lib.run_ops(self.ops, self.n_ops, stream_ptr)
@@ -400,8 +408,6 @@ class DiffusionAttnUnet1D(nn.Module):
         super().__init__()
         if learned_resample:
             raise NotImplementedError("learned_resample=True (Downsample1d_2/Upsample1d_2) is not on the MI355X hot path yet")
-        if cond_dim or cond_noise_aug:
-            raise NotImplementedError("conditioning inputs are not on the MI355X hot path yet")
         if kernel_size != 5:
             raise NotImplementedError("libadk convolution kernels are built for kernel_size=5")
         if depth < 2:
@@ -409,7 +415,9 @@ class DiffusionAttnUnet1D(nn.Module):
         self.io_channels, self.depth, self.n_attn_layers = io_channels, depth, n_attn_layers
         self.c_mults = list(c_mults)
         self.pqmf_bands, self.kernel_size = pqmf_bands, kernel_size
-        self.cond_noise_aug = cond_noise_aug
+        self.cond_dim, self.cond_noise_aug = cond_dim, cond_noise_aug
+        if cond_noise_aug:                 # reference :77-78 (Sobol level per sample when no cond_aug_scale is given)
+            self.rng = torch.quasirandom.SobolEngine(1, scramble=True)
 
         # construction order == reference (:80-133): pqmf, timestep_embed, then levels innermost-first
         if pqmf_bands > 1:
@@ -432,8 +440,9 @@ class DiffusionAttnUnet1D(nn.Module):
                 mods += [conv_block(c, c, c_prev), attn(c_prev), Upsample1d(kernel="cubic")]
                 block = SkipBlock(*mods)
             else:
+                cond_embed_dim = 32 if cond_noise_aug else 16
                 block = nn.Sequential(
-                    conv_block(io_channels * pqmf_bands + cond_dim + 16, c, c),
+                    conv_block(io_channels * pqmf_bands + cond_dim + cond_embed_dim, c, c),
                     conv_block(c, c, c),
                     conv_block(c, c, c),
                     block,
@@ -491,18 +500,41 @@ class DiffusionAttnUnet1D(nn.Module):
             return torch.bfloat16
         return torch.float32
 
-    def plan_for(self, B, T, dtype, device, t_table=None):
-        key = (B, T, dtype, str(device), t_table)
+    def plan_for(self, B, T, dtype, device, t_table=None, cond_len=0):
+        key = (B, T, dtype, str(device), t_table, cond_len)
         plan = self._plans.get(key)
         if plan is None:
-            plan = _Plan(self, B, T, dtype, device, t_table)
+            plan = _Plan(self, B, T, dtype, device, t_table, cond_len)
             self._plans[key] = plan
         return plan
 
+    def prepare_cond(self, x, cond, cond_aug_scale=None):
+        """Validate ``cond`` like the first conv of the reference would (channel count) and apply the noise
+        augmentation draws of diffusion_decoder.py:153-160 (level: Sobol or ``cond_aug_scale``; noise: torch's device
+        generator; the kernel adds noise * level after its interpolation).  Returns (cond fp32 contiguous or None,
+        per-sample levels fp32 [B] or None, noise fp32 [B, cond_dim, L] or None)."""
+        if cond is None:
+            if self.cond_dim or self.cond_noise_aug:
+                raise RuntimeError(f"this model was built with cond_dim={self.cond_dim}, cond_noise_aug="
+                                   f"{self.cond_noise_aug}: forward() needs `cond` (the reference fails in its first "
+                                   "conv with a channel mismatch)")
+            return None, None, None
+        if cond.dim() != 3 or cond.shape[0] != x.shape[0] or cond.shape[1] != self.cond_dim or self.cond_dim == 0:
+            raise RuntimeError(f"expected cond of shape [{x.shape[0]}, {self.cond_dim}, Lc], got {tuple(cond.shape)} "
+                               "(the reference fails in its first conv with a channel mismatch)")
+        cond = cond.detach().to(device=x.device, dtype=torch.float32)
+        aug = noise = None
+        if self.cond_noise_aug:
+            if cond_aug_scale is None:
+                aug = self.rng.draw(cond.shape[0])[:, 0].to(cond)
+            else:
+                aug = torch.tensor([cond_aug_scale]).repeat([cond.shape[0]]).to(cond)
+            aug = aug.contiguous()
+            noise = torch.randn(cond.shape[0], cond.shape[1], x.shape[2] // self.pqmf_bands, device=x.device)
+        return cond.contiguous(), aug, noise
+
     @torch.no_grad()
     def forward(self, x, t, cond=None, cond_aug_scale=None):
-        if cond is not None or cond_aug_scale is not None:
-            raise NotImplementedError("conditioning inputs are not on the MI355X hot path yet")
         if not x.is_cuda:
             raise RuntimeError("DiffusionAttnUnet1D (MI355X build) runs on ROCm devices only; there is no CPU path")
         self.check_input(x)
@@ -511,8 +543,10 @@ class DiffusionAttnUnet1D(nn.Module):
         tin = t.detach().to(device=x.device, dtype=torch.float32).contiguous()
         if tin.numel() != x.shape[0]:
             raise ValueError(f"t must have one entry per batch item, got {tuple(t.shape)}")
-        plan = self.plan_for(x.shape[0], x.shape[2], dtype, x.device)
+        cin, aug, noise = self.prepare_cond(x, cond, cond_aug_scale)
+        plan = self.plan_for(x.shape[0], x.shape[2], dtype, x.device, cond_len=cin.shape[2] if cin is not None else 0)
         out = torch.empty_like(xin)
-        plan.bind(xin.data_ptr(), tin.data_ptr(), out.data_ptr())
+        plan.bind(xin.data_ptr(), tin.data_ptr(), out.data_ptr(), cin.data_ptr() if cin is not None else 0,
+                  aug.data_ptr() if aug is not None else 0, noise.data_ptr() if noise is not None else 0)
         plan.run(torch.cuda.current_stream(x.device).cuda_stream)
         return out

@@ -138,6 +138,17 @@ int adk_attn1d(int dtype, int B, int L, int P, int C, const void *qkv, void *y, 
 int adk_pack_input(int dtype, int B, int L, int P, int Cx, const float *x, const float *t,
                    const int32_t *step, int t_stride, const float *fw, void *y, void *stream);
 
+/* The same with the conditioning inputs of DiffusionAttnUnet1D.forward (decoders/diffusion_decoder.py:148-169):
+ *   cond f32 [B,Cc,Lc] is resampled to L like F.interpolate(mode='linear', align_corners=False) (:150-151);
+ *   aug_level f32 [B] or NULL: with cond_noise_aug a second Fourier embedding of the noise level goes in front
+ *   of cond (:162-165) and cond += aug_noise * aug_level[b] (:160), aug_noise f32 [B,Cc,L] = the caller's N(0,1)
+ *   draw (or NULL: no noise added).
+ *   y CPL [B, roundup(Cx + 16 (+16) + Cc, 32), L] = [x | emb(t) | (emb(aug)) | cond | 0...]. */
+int adk_pack_input_cond(int dtype, int B, int L, int P, int Cx, const float *x, const float *t,
+                        const int32_t *step, int t_stride, const float *fw,
+                        const float *cond, int Cc, int Lc, const float *aug_level, const float *aug_noise,
+                        void *y, void *stream);
+
 /* CPL f32 [B,C,L] -> NCL f32 [B,C,L] (output boundary of the network). */
 int adk_unpack_output(int B, int L, int P, int C, const float *x, float *y, void *stream);
 

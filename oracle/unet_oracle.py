@@ -138,10 +138,10 @@ def net_forward(sd, cfg, h):
     return res_conv_block(sd, "net.6.", h, is_last=True)
 
 
-def unet_forward(sd, cfg, x, t, cond=None):
-    """DiffusionAttnUnet1D.forward (diffusion_decoder.py:139-176), cond_noise_aug=False."""
-    if cfg["cond_noise_aug"]:
-        raise NotImplementedError("cond_noise_aug draws RNG; outside parity scope")
+def unet_forward(sd, cfg, x, t, cond=None, cond_aug_scale=None):
+    """DiffusionAttnUnet1D.forward (diffusion_decoder.py:139-176).  With cond_noise_aug the level must be given
+    (``cond_aug_scale``; the reference's Sobol draw at :155-156 is random) and the noise is torch's CPU randn, so
+    only cond_aug_scale = 0 is bit-reproducible."""
     bands = cfg["pqmf_bands"]
     if bands > 1:
         x = pqmf_oracle.analysis(x, sd["pqmf.forward_conv.weight"], bands)
@@ -151,6 +151,13 @@ def unet_forward(sd, cfg, x, t, cond=None):
     if cond is not None:
         if cond.shape[2] != x.shape[2]:
             cond = F.interpolate(cond, (x.shape[2],), mode="linear", align_corners=False)
+        if cfg["cond_noise_aug"]:                              # :153-167
+            if cond_aug_scale is None:
+                raise NotImplementedError("oracle needs an explicit cond_aug_scale (the reference draws it from Sobol)")
+            aug = torch.tensor([cond_aug_scale]).repeat([cond.shape[0]]).to(cond)
+            cond = cond + torch.randn_like(cond) * aug[:, None, None]
+            aug_emb = fourier_features(sd["timestep_embed.weight"], aug)
+            inputs.append(aug_emb[..., None].repeat([1, 1, x.shape[2]]))
         inputs.append(cond)
     out = net_forward(sd, cfg, torch.cat(inputs, dim=1))
     if bands > 1:

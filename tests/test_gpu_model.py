@@ -176,3 +176,47 @@ def test_diffae_sampler_variant():
     zs = sig.mean(dim=2, keepdim=True)
     want = A.sample(lambda xx, tt: m(xx + 0.1 * zs, tt), x0, 4, 0)
     assert torch.equal(got, want) and torch.isfinite(got).all()
+
+
+@pytest.mark.parametrize("name", ["tiny_d3_cond.npz", "tiny_d3_cond_samelen.npz", "tiny_d3_cond_aug0.npz"])
+def test_conditioning_path_vs_reference_golden(name):
+    """cond (linear interpolation to the signal length inside pack_input), optional noise-aug level
+    embedding; forward and DDIM (fused captured loop when cond is constant) vs goldens captured from the reference."""
+    import audio_diffusion_amd as A
+    dev = torch.device("cuda:0")
+    z = load_npz(name)
+    m = build(z, dev)
+    x, t, cond = (torch.from_numpy(z[k]).to(dev) for k in ("x", "t", "cond"))
+    extra = dict(cond=cond)
+    if float(z["aug_scale"]) >= 0:
+        extra["cond_aug_scale"] = float(z["aug_scale"])
+    m.compute_dtype = torch.float32
+    y = m(x, t, **extra)
+    assert rel_err(y, torch.from_numpy(z["y"])) <= 1e-4
+    pred = A.sample(m, x, int(z["steps"]), 0, **extra)
+    assert rel_err(pred, torch.from_numpy(z["pred"])) <= 1e-4 and snr_db(pred, torch.from_numpy(z["pred"])) >= 60.0
+    m.compute_dtype = torch.bfloat16
+    yb = m(x, t, **extra).cpu()
+    ref = torch.from_numpy(z["y"])
+    assert float((yb - ref).norm() / ref.norm()) <= 2e-2
+    with pytest.raises(RuntimeError):
+        m(x, t)                                            # cond missing: the reference fails on the channel count
+    with pytest.raises(RuntimeError):
+        m(x, t, cond=cond[:, :1])
+
+
+def test_cond_noise_aug_draws_noise():
+    """cond_noise_aug with a non-zero level: the result moves with the RNG draw and is reproducible under a seed."""
+    dev = torch.device("cuda:0")
+    z = load_npz("tiny_d3_cond_aug0.npz")
+    m = build(z, dev)
+    m.compute_dtype = torch.float32
+    x, t, cond = (torch.from_numpy(z[k]).to(dev) for k in ("x", "t", "cond"))
+    torch.manual_seed(5)
+    a = m(x, t, cond=cond, cond_aug_scale=0.3)
+    torch.manual_seed(5)
+    b = m(x, t, cond=cond, cond_aug_scale=0.3)
+    c = m(x, t, cond=cond, cond_aug_scale=0.3)
+    assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(c).all()
+    d = m(x, t, cond=cond)                                 # Sobol-drawn level per sample (reference :155-156)
+    assert torch.isfinite(d).all()

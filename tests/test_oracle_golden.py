@@ -120,3 +120,20 @@ def test_attention_level_rule():
     assert U.attn_levels(U.make_config()) == list(range(7, 15))
     assert U.attn_levels(U.make_config(depth=3, n_attn_layers=1, c_mults=[32, 32, 64])) == [2, 3]
     assert U.attn_levels(U.make_config(n_attn_layers=0)) == []
+
+
+@pytest.mark.parametrize("name", ["tiny_d3_cond.npz", "tiny_d3_cond_samelen.npz", "tiny_d3_cond_aug0.npz"])
+def test_conditioning_path(name):
+    """cond interpolated to the signal length, optional noise-aug level embedding
+    (decoders/diffusion_decoder.py:148-169), forward + 4-step DDIM with cond forwarded through **extra_args."""
+    import json
+    from oracle import unet_oracle as U, sampling_oracle as S
+    z = load_npz(name)
+    cfg = U.make_config(**json.loads(bytes(z["cfg"]).decode()))
+    model = U.make_model_fn(sub_sd(z, "sd/"), cfg)
+    x, t, cond = (torch.from_numpy(z[k]) for k in ("x", "t", "cond"))
+    extra = dict(cond=cond)
+    if float(z["aug_scale"]) >= 0:
+        extra["cond_aug_scale"] = float(z["aug_scale"])
+    assert rel_err(model(x, t, **extra), torch.from_numpy(z["y"])) <= 1e-6
+    assert rel_err(S.ddim_sample(model, x, int(z["steps"]), 0, **extra), torch.from_numpy(z["pred"])) <= 1e-5

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate golden vectors by IMPORTING the reference (this container only).
 
-Run:  python tools/make_goldens.py [--tier B T F] [--ref /root/reference]
+Run:  python tools/make_goldens.py [--tier B T C F] [--ref /root/reference]
 Writes small fixtures (inputs + expected outputs, never source text) to tests/golden/.
 
 The reference's hot path is Python; three of its imports are unavailable or have drifted in this
@@ -212,6 +212,40 @@ def tier_tiny(Model, sampling):
                      (3, 1, 512), seed=30)
 
 
+def run_cond_golden(name, Model, sampling, kwargs, x_shape, cond_len, seed, aug_scale=None, steps=4):
+    """Conditioning path (decoders/diffusion_decoder.py:148-169): cond is linearly interpolated to the signal
+    length; with cond_noise_aug the level is fixed to ``aug_scale`` (0.0 keeps the call deterministic: the
+    reference multiplies its randn by it) and a second Fourier embedding is inserted before cond."""
+    import contextlib
+    import io
+    torch.manual_seed(seed)
+    m = Model(**kwargs).eval()
+    torch.manual_seed(seed + 1)
+    x = torch.randn(*x_shape)
+    t = torch.rand(x_shape[0])
+    cond = torch.randn(x_shape[0], kwargs["cond_dim"], cond_len)
+    extra = dict(cond=cond)
+    if aug_scale is not None:
+        extra["cond_aug_scale"] = aug_scale
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        y = m(x, t, **extra)
+        pred = sampling.sample(m, x, steps, 0, **extra)
+    npz(name, x=x, t=t, cond=cond, y=y, pred=pred, seed=np.int64(seed), steps=np.int64(steps),
+        aug_scale=np.float32(-1.0 if aug_scale is None else aug_scale),
+        cfg=np.bytes_(json.dumps(dict(kwargs)).encode()), **sd_arrays(m.state_dict()))
+
+
+def tier_cond(Model, sampling):
+    print("tier C: conditioning path (SURVEY 8 f1)")
+    run_cond_golden("tiny_d3_cond.npz", Model, sampling,
+                    dict(depth=3, c_mults=[32, 32, 64], n_attn_layers=1, cond_dim=4), (2, 2, 1024), 37, seed=40)
+    run_cond_golden("tiny_d3_cond_samelen.npz", Model, sampling,
+                    dict(depth=3, c_mults=[32, 32, 64], n_attn_layers=0, cond_dim=32), (2, 2, 512), 512, seed=41)
+    run_cond_golden("tiny_d3_cond_aug0.npz", Model, sampling,
+                    dict(depth=3, c_mults=[32, 32, 64], n_attn_layers=1, cond_dim=3, cond_noise_aug=True),
+                    (2, 2, 1024), 100, seed=42, aug_scale=0.0)
+
+
 def tier_full(Model, sampling):
     print("tier F: full 221M-param uncond model (seeds 0/1), digests + 10-step output")
     torch.manual_seed(0)
@@ -255,7 +289,7 @@ def tier_full(Model, sampling):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--tier", nargs="+", default=["B", "T", "F"])
+    ap.add_argument("--tier", nargs="+", default=["B", "T", "C", "F"])
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     P, Model, sampling, blocks = import_reference(a.ref)
@@ -263,6 +297,8 @@ def main():
         tier_blocks(P, blocks, sampling)
     if "T" in a.tier:
         tier_tiny(Model, sampling)
+    if "C" in a.tier:
+        tier_cond(Model, sampling)
     if "F" in a.tier:
         tier_full(Model, sampling)
 

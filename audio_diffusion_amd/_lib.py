@@ -14,7 +14,7 @@ ADK_F32, ADK_BF16 = 0, 1
 
 OP_CONV, OP_GN_APPLY, OP_GN_STATS, OP_FIR_DOWN, OP_FIR_UP, OP_ATTN = 1, 2, 3, 4, 5, 6
 OP_PACK_INPUT, OP_UNPACK_OUTPUT, OP_PQMF_ANALYSIS, OP_PQMF_SYNTHESIS = 7, 8, 9, 10
-OP_DDIM_UPDATE, OP_STEP_ADVANCE, OP_AUDIO_TO_INT16 = 11, 12, 13
+OP_DDIM_UPDATE, OP_STEP_ADVANCE, OP_AUDIO_TO_INT16, OP_SPACE_TO_DEPTH, OP_DEPTH_TO_SPACE = 11, 12, 13, 14, 15
 
 FLAG_GELU, FLAG_OUT_F32, FLAG_NOISE = 1, 2, 4
 
@@ -39,7 +39,7 @@ EXPORTS = [
     "adk_version", "adk_last_error", "adk_run_plan", "adk_validate_plan", "adk_partials_count", "adk_conv_postile", "adk_conv_cotile_used", "adk_conv_cotile",
     "adk_conv1d", "adk_gn_apply", "adk_gn_stats", "adk_fir_down2", "adk_fir_up2", "adk_attn1d",
     "adk_pack_input", "adk_pack_input_cond", "adk_unpack_output", "adk_pqmf_analysis", "adk_pqmf_synthesis",
-    "adk_ddim_update", "adk_step_advance", "adk_audio_to_int16",
+    "adk_ddim_update", "adk_step_advance", "adk_audio_to_int16", "adk_space_to_depth", "adk_depth_to_space",
 ]
 
 _lib = None
@@ -84,6 +84,8 @@ def load():
     lib.adk_ddim_update.argtypes = [u32, i64, vp, vp, vp, vp, vp, vp, vp]
     lib.adk_step_advance.argtypes = [vp, vp]
     lib.adk_audio_to_int16.argtypes = [i32, i32, i32, vp, vp, vp]
+    lib.adk_space_to_depth.argtypes = [i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.adk_depth_to_space.argtypes = [i32, i32, i32, i32, i32, i32, vp, vp, vp]
     for name in EXPORTS:
         if name not in ("adk_last_error",):
             getattr(lib, name).restype = C.c_int

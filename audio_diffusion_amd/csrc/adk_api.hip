@@ -20,6 +20,7 @@ int launch_unpack_output(const adk_op& op, hipStream_t st);
 int launch_ddim_update(const adk_op& op, hipStream_t st);
 int launch_step_advance(const adk_op& op, hipStream_t st);
 int launch_audio_to_int16(const adk_op& op, hipStream_t st);
+int launch_phase_shuffle(const adk_op& op, hipStream_t st, bool to_depth);
 
 static thread_local char g_err[512] = "";
 
@@ -52,7 +53,7 @@ static int validate(const adk_op& o)
     case ADK_OP_CONV: {
         if ((rc = check_geo(o, "conv1d"))) return rc;
         const int cb = cb_of(o.dtype);
-        REQUIRE(o.taps == 1 || o.taps == 5, "conv1d: taps=%d unsupported (1 or 5)", o.taps);
+        REQUIRE(o.taps == 1 || o.taps == 3 || o.taps == 5 || o.taps == 7, "conv1d: taps=%d unsupported (1, 3, 5 or 7)", o.taps);
         REQUIRE(o.P >= o.taps / 2, "conv1d: halo P=%d < taps/2=%d", o.P, o.taps / 2);
         REQUIRE(o.Cin >= cb && o.Cin % cb == 0, "conv1d: Cin=%d not a multiple of %d", o.Cin, cb);
         REQUIRE(o.Cout >= 1, "conv1d: Cout=%d", o.Cout);
@@ -122,6 +123,18 @@ static int validate(const adk_op& o)
     case ADK_OP_STEP_ADVANCE:
         REQUIRE(o.y, "step_advance: null counter");
         return ADK_OK;
+    case ADK_OP_SPACE_TO_DEPTH:
+    case ADK_OP_DEPTH_TO_SPACE: {
+        if ((rc = check_geo(o, "phase_shuffle"))) return rc;
+        const int cb = cb_of(o.dtype);
+        REQUIRE(o.x && o.y && o.x != o.y, "phase_shuffle: null or aliased tensors");
+        REQUIRE(o.i0 >= 1 && o.i0 <= 64, "phase_shuffle: factor %d out of range [1,64]", o.i0);
+        REQUIRE(o.Cin >= cb && o.Cin % cb == 0, "phase_shuffle: C=%d must be a multiple of %d", o.Cin, cb);
+        REQUIRE(o.P <= 64, "phase_shuffle: halo %d too large", o.P);
+        if (o.kind == ADK_OP_SPACE_TO_DEPTH) REQUIRE(o.L % o.i0 == 0, "space_to_depth: L=%d not a multiple of %d", o.L, o.i0);
+        REQUIRE((long long)o.B * ((long long)o.L * o.i0 + 2 * o.P) < (1LL << 25), "phase_shuffle: too many rows");
+        return ADK_OK;
+    }
     case ADK_OP_AUDIO_TO_INT16:
         REQUIRE(o.B >= 1 && o.Cin >= 1 && o.L >= 1 && o.x && o.y, "audio_to_int16: bad arguments");
         REQUIRE((long long)o.B * o.Cin <= 65535, "audio_to_int16: B*C=%lld exceeds 65535", (long long)o.B * o.Cin);
@@ -147,6 +160,8 @@ static int dispatch(const adk_op& o, hipStream_t st)
     case ADK_OP_DDIM_UPDATE: return launch_ddim_update(o, st);
     case ADK_OP_STEP_ADVANCE: return launch_step_advance(o, st);
     case ADK_OP_AUDIO_TO_INT16: return launch_audio_to_int16(o, st);
+    case ADK_OP_SPACE_TO_DEPTH: return launch_phase_shuffle(o, st, true);
+    case ADK_OP_DEPTH_TO_SPACE: return launch_phase_shuffle(o, st, false);
     }
     return ADK_EINVAL;
 }
@@ -314,6 +329,20 @@ int adk_ddim_update(uint32_t flags, int64_t n, float* x, const float* v, const f
     adk_op o = zero_op(ADK_OP_DDIM_UPDATE, ADK_F32);
     o.flags = flags; o.i0 = (int32_t)(n & 0x7fffffff); o.i1 = (int32_t)(n >> 31);
     o.y = x; o.x = v; o.residual = noise; o.aux1 = pred; o.aux0 = coef; o.bias = reinterpret_cast<const float*>(step);
+    return adk_run_plan(&o, 1, stream);
+}
+
+int adk_space_to_depth(int dtype, int B, int L, int P, int C, int factor, const void* x, void* y, void* stream)
+{
+    adk_op o = zero_op(ADK_OP_SPACE_TO_DEPTH, dtype);
+    o.B = B; o.L = L; o.P = P; o.Cin = C; o.i0 = factor; o.x = x; o.y = y;
+    return adk_run_plan(&o, 1, stream);
+}
+
+int adk_depth_to_space(int dtype, int B, int L, int P, int C, int factor, const void* x, void* y, void* stream)
+{
+    adk_op o = zero_op(ADK_OP_DEPTH_TO_SPACE, dtype);
+    o.B = B; o.L = L; o.P = P; o.Cin = C; o.i0 = factor; o.x = x; o.y = y;
     return adk_run_plan(&o, 1, stream);
 }
 

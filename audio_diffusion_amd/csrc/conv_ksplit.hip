@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, (TCO * TPOS >= 4 ? 1 : 2)) void conv_ksplit_ke
 template <typename T, typename TO, int TAPS, int TCO, int TPOS>
 static int launch_ks(const adk_op& op, hipStream_t st)
 {
-    constexpr int DEPTH = TAPS == 1 ? 4 : (TCO * TPOS == 1 ? 2 : 1);
+    constexpr int DEPTH = TAPS == 1 ? 4 : ((TCO * TPOS == 1 && TAPS <= 5) ? 2 : 1);
     ConvArgs a;
     conv_fill_args(op, TCO * 32, TPOS * 32, a);
     const size_t lds = (size_t)TCO * TPOS * 16384;
@@ -196,6 +196,8 @@ static int launch_ks_taps(const adk_op& op, hipStream_t st)
 {
     if (op.taps == 1) return launch_ks_tiles<T, TO, 1>(op, st);
     if (op.taps == 5) return launch_ks_tiles<T, TO, 5>(op, st);
+    if (op.taps == 3) return launch_ks_tiles<T, TO, 3>(op, st);
+    if (op.taps == 7) return launch_ks_tiles<T, TO, 7>(op, st);
     return ADK_EINVAL;
 }
 

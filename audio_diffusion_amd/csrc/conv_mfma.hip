@@ -365,7 +365,7 @@ __global__ __launch_bounds__(WCO * WPOS * 64, 2) void conv_mfma_kernel(const Con
 
     for (int kc = 0; kc < a.nchunks; ++kc) {
         const bool last = kc == a.nchunks - 1;
-        ADK_PHASE(0) ADK_PHASE(1) ADK_PHASE(2) ADK_PHASE(3) ADK_PHASE(4)
+        ADK_PHASE(0) ADK_PHASE(1) ADK_PHASE(2) ADK_PHASE(3) ADK_PHASE(4) ADK_PHASE(5) ADK_PHASE(6)
     }
 #undef ADK_PHASE
 #undef ADK_LOAD_FRAGS
@@ -460,6 +460,8 @@ static int launch_taps(const adk_op& op, hipStream_t st)
 {
     if (op.taps == 1) return launch_tiles<T, TO, 1>(op, st);
     if (op.taps == 5) return launch_tiles<T, TO, 5>(op, st);
+    if (op.taps == 3) return launch_tiles<T, TO, 3>(op, st);      // learned resamplers (blocks/blocks.py:214-255)
+    if (op.taps == 7) return launch_tiles<T, TO, 7>(op, st);      // kernel_size=7 models (train_uncond.py:97-106)
     return ADK_EINVAL;
 }
 

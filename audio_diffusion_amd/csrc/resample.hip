@@ -140,3 +140,55 @@ int launch_fir(const adk_op& op, hipStream_t st, bool up)
     if (op.dtype == ADK_F32) return up ? launch_fir_t<float, true>(op, st) : launch_fir_t<float, false>(op, st);
     return up ? launch_fir_t<bf16_t, true>(op, st) : launch_fir_t<bf16_t, false>(op, st);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Learned resamplers (reference blocks/blocks.py:214-255: Downsample1d_2 = strided Conv1d(k = 2f+1, stride f,
+// padding f), Upsample1d_2 = ConvTranspose1d(k = 2f, stride f)) are run as a PHASE SHUFFLE + a 3-tap stride-1
+// convolution on the MFMA kernels (the weight repack is host-side, audio_diffusion_amd/unet.py):
+//   space_to_depth: y[p*C + c][m] = x[c][m*f + p]        [B, C, L]   -> [B, f*C, L/f]   (before the down conv)
+//   depth_to_space: y[c][j*f + s] = x[s*C + c][j]        [B, f*C, L] -> [B, C, L*f]     (after the up conv)
+// With C a multiple of the 64-byte channel chunk a plane maps to a plane, so both are row copies (HBM-bound).
+struct ShuffleArgs { const void* x; void* y; int B, Li, Lo, P, f, planes_c; };   // planes_c = planes of C channels
+
+template <bool TO_DEPTH>
+__global__ __launch_bounds__(256) void phase_shuffle_kernel(const ShuffleArgs a)
+{
+    const int q = threadIdx.x & 3, r0 = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const int plane_o = blockIdx.y, b = blockIdx.z;
+    const int Lpi = a.Li + 2 * a.P, Lpo = a.Lo + 2 * a.P;
+    const long long Mi = (long long)a.B * Lpi, Mo = (long long)a.B * Lpo;
+    unsigned char* yb = reinterpret_cast<unsigned char*>(a.y) + ((long long)plane_o * Mo + (long long)b * Lpo) * 64 + q * 16;
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x) + q * 16;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    if (r0 < a.Lo) {
+        long long src;
+        if (TO_DEPTH) {                       // output plane (p, pc): phase p of input plane pc
+            const int p = plane_o / a.planes_c, pc = plane_o % a.planes_c;
+            src = (long long)pc * Mi + (long long)b * Lpi + a.P + (long long)r0 * a.f + p;
+        } else {                              // output row j*f + s of plane pc: row j of input plane (s, pc)
+            const int j = r0 / a.f, s = r0 % a.f;
+            src = (long long)(s * a.planes_c + plane_o) * Mi + (long long)b * Lpi + a.P + j;
+        }
+        *reinterpret_cast<uint4*>(yb + (long long)(a.P + r0) * 64) = *reinterpret_cast<const uint4*>(xb + src * 64);
+    }
+    if (blockIdx.x == 0 && (threadIdx.x >> 2) < a.P) {          // halo rows of the output
+        const int r = threadIdx.x >> 2;
+        *reinterpret_cast<uint4*>(yb + (long long)r * 64) = z;
+        *reinterpret_cast<uint4*>(yb + (long long)(a.P + a.Lo + r) * 64) = z;
+    }
+}
+
+int launch_phase_shuffle(const adk_op& op, hipStream_t st, bool to_depth)
+{
+    const int CB = op.dtype == ADK_F32 ? 16 : 32;
+    ShuffleArgs a;
+    a.x = op.x; a.y = op.y; a.B = op.B; a.P = op.P; a.f = op.i0;
+    a.planes_c = op.Cin / CB;                 // op.Cin = C (channels of the NON-folded tensor)
+    a.Li = op.L;
+    a.Lo = to_depth ? op.L / a.f : op.L * a.f;
+    const int planes_o = to_depth ? a.planes_c * a.f : a.planes_c;
+    dim3 grid((a.Lo + 63) / 64, planes_o, op.B);
+    if (to_depth) hipLaunchKernelGGL(phase_shuffle_kernel<true>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(phase_shuffle_kernel<false>, grid, dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
+}

@@ -50,7 +50,9 @@ enum {
     ADK_OP_PQMF_SYNTHESIS = 10, /* CachedPQMF.inverse: diffusion/pqmf.py:285-302                     */
     ADK_OP_DDIM_UPDATE = 11,  /* per-step v-DDIM update: diffusion/sampling.py:34-52                 */
     ADK_OP_STEP_ADVANCE = 12, /* device-side step counter ++ (lets one hipGraph replay every step)   */
-    ADK_OP_AUDIO_TO_INT16 = 13 /* demo output stage: train_uncond.py:182-187                          */
+    ADK_OP_AUDIO_TO_INT16 = 13, /* demo output stage: train_uncond.py:182-187                         */
+    ADK_OP_SPACE_TO_DEPTH = 14, /* phase fold in front of Downsample1d_2's strided conv: blocks/blocks.py:214-226 */
+    ADK_OP_DEPTH_TO_SPACE = 15  /* phase unfold behind Upsample1d_2's transposed conv:   blocks/blocks.py:229-255 */
 };
 
 /* flags */
@@ -170,6 +172,15 @@ int adk_ddim_update(uint32_t flags, int64_t n, float *x, const float *v, const f
                     const float *coef, const int32_t *step, void *stream);
 
 int adk_step_advance(int32_t *step, void *stream);
+
+/* Learned resamplers (blocks/blocks.py:214-255).  Downsample1d_2 = Conv1d(k = 2f+1, stride f, padding f) and
+ * Upsample1d_2 = ConvTranspose1d(k = 2f, stride f) are each ONE 3-tap stride-1 adk_conv1d on phase-folded data
+ * (weights re-indexed on the host: audio_diffusion_amd/unet.py), with these row shuffles around it:
+ *   space_to_depth: x CPL [B,C,L]     -> y CPL [B,f*C,L/f],  y[p*C + c][m] = x[c][m*f + p]
+ *   depth_to_space: x CPL [B,f*C,L]   -> y CPL [B,C,L*f],    y[c][j*f + s] = x[s*C + c][j]
+ * C must be a multiple of the channel chunk (16 f32 / 32 bf16); L is the INPUT length. */
+int adk_space_to_depth(int dtype, int B, int L, int P, int C, int factor, const void *x, void *y, void *stream);
+int adk_depth_to_space(int dtype, int B, int L, int P, int C, int factor, const void *x, void *y, void *stream);
 
 /* Replaces the output stage every caller of sample() applies (train_uncond.py:182-187, generate.py):
  *   rearrange(fakes, 'b d n -> d (b n)').clamp(-1, 1).mul(32767).to(torch.int16)

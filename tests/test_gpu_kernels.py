@@ -62,6 +62,12 @@ CONV_CASES = [
     (2, 100, 64, 128, 1, True, True),      # 1x1 at 64 < L <= 128: pipelined, where k=5 uses the k-split kernel
     (2, 100, 64, 128, 5, True, True),
     (3, 200, 128, 256, 5, True, False),    # L <= 256: pipelined 128x64 tile, ragged
+    # kernel_size = 7 models and the 3-tap convolutions of the learned resamplers, halo P = 3
+    (2, 2100, 64, 128, 7, True, True),
+    (2, 300, 96, 160, 7, True, False),
+    (4, 24, 128, 128, 7, True, False),
+    (2, 4100, 64, 256, 3, True, False),
+    (3, 100, 256, 128, 3, True, True),
 ]
 
 
@@ -71,7 +77,7 @@ def test_conv1d(env, dt, case):
     lib, _lib, layout, dev = env
     dtype, adk, tol = DT[dt]
     B, L, Cin, Cout, taps, has_bias, has_res = case
-    P = 2
+    P = max(2, taps // 2)
     cb = layout.chunk(dtype)
     g = torch.Generator().manual_seed(hash(case) % 1000)
     x = torch.randn(B, Cin, L, generator=g)
@@ -124,7 +130,7 @@ def test_conv1d_rejects_bad_shapes(env):
     assert lib.adk_conv1d(0, 0, 1, 64, 2, 20, 32, 32, 5, p, p, None, None, p, None, sp()) == -1   # Cin not chunked
     assert b"Cin" in lib.adk_last_error()
     assert lib.adk_conv1d(0, 0, 1, 64, 1, 32, 32, 32, 5, p, p, None, None, p, None, sp()) == -1   # halo < taps/2
-    assert lib.adk_conv1d(0, 0, 1, 64, 2, 32, 32, 32, 3, p, p, None, None, p, None, sp()) == -1   # taps
+    assert lib.adk_conv1d(0, 0, 1, 64, 2, 32, 32, 32, 4, p, p, None, None, p, None, sp()) == -1   # taps
     assert lib.adk_conv1d(0, 0, 1, 64, 2, 32, 64, 64, 5, p, p, None, None, p, None, sp()) == -1   # CoutPad % 128
     assert lib.adk_conv1d(0, 0, 1, 64, 2, 32, 32, 32, 5, None, p, None, None, p, None, sp()) == -1
 

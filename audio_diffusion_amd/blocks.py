@@ -105,3 +105,60 @@ class Upsample1d(_NoCompute):
         taps = torch.tensor(FIR_TABLES[kernel]) * 2
         self.pad = taps.shape[0] // 2 - 1
         self.register_buffer("kernel", taps)
+
+
+def Downsample1d_2(in_channels, out_channels, factor, kernel_multiplier=2):
+    """Learned downsampler, key-for-key the reference factory (blocks/blocks.py:214-226): a strided nn.Conv1d
+    (parameter container here; libadk runs it as space_to_depth + a 3-tap convolution, see fold_down_weight)."""
+    assert kernel_multiplier % 2 == 0, "Kernel multiplier must be even"
+    if kernel_multiplier != 2:
+        raise NotImplementedError("libadk folds Downsample1d_2 for kernel_multiplier=2 (the reference default)")
+    return nn.Conv1d(in_channels=in_channels, out_channels=out_channels, kernel_size=factor * kernel_multiplier + 1,
+                     stride=factor, padding=factor * (kernel_multiplier // 2))
+
+
+def Upsample1d_2(in_channels, out_channels, factor, use_nearest=False):
+    """Learned upsampler, key-for-key the reference factory (blocks/blocks.py:229-255)."""
+    if factor == 1:
+        return nn.Conv1d(in_channels=in_channels, out_channels=out_channels, kernel_size=3, padding=1)
+    if use_nearest:
+        raise NotImplementedError("use_nearest=True is never used by DiffusionAttnUnet1D")
+    return nn.ConvTranspose1d(in_channels=in_channels, out_channels=out_channels, kernel_size=factor * 2,
+                              stride=factor, padding=factor // 2 + factor % 2, output_padding=factor % 2)
+
+
+def fold_down_weight(w, factor):
+    """Conv1d(k = 2f+1, stride f, padding f) == 3-tap stride-1 conv over the phase-folded input
+    x'[p*C + c][m] = x[c][m*f + p]:   y[m] = sum_{q,p} w[:, :, q*f + p] x'[p][m - 1 + q]   (q*f + p <= 2f).
+    w [Co, C, 2f+1] -> [Co, f*C, 3]."""
+    co, c, k = w.shape
+    f = factor
+    assert k == 2 * f + 1
+    out = w.new_zeros(co, f, c, 3)
+    for q in range(3):
+        for p in range(f):
+            if q * f + p <= 2 * f:
+                out[:, p, :, q] = w[:, :, q * f + p]
+    return out.reshape(co, f * c, 3)
+
+
+def fold_up_weight(wt, bias, factor):
+    """ConvTranspose1d(k = 2f, stride f, padding pad = f//2 + f%2, output_padding f%2) == 3-tap stride-1 conv
+    producing f phases per input position, y[co][j*f + s] = z[s*Co + co][j]:  with r = (s + pad) mod f,
+        r >= pad:  z[s][j] = wt[:, :, r + f]^T x[j - 1] + wt[:, :, r]^T x[j]
+        r <  pad:  z[s][j] = wt[:, :, r + f]^T x[j]     + wt[:, :, r]^T x[j + 1]
+    wt [C, Co, 2f] (ConvTranspose layout) -> weight [f*Co, C, 3], bias [f*Co]."""
+    c, co, k = wt.shape
+    f = factor
+    assert k == 2 * f
+    pad = f // 2 + f % 2
+    out = wt.new_zeros(f, co, c, 3)
+    for s in range(f):
+        r = (s + pad) % f
+        hi, lo = wt[:, :, r + f].t(), wt[:, :, r].t()          # [Co, C]
+        if r >= pad:
+            out[s, :, :, 0], out[s, :, :, 1] = hi, lo
+        else:
+            out[s, :, :, 1], out[s, :, :, 2] = hi, lo
+    b = None if bias is None else bias.repeat(f)
+    return out.reshape(f * co, c, 3), b

@@ -17,7 +17,8 @@ import torch
 from torch import nn
 
 from . import _lib
-from .blocks import (ResConvBlock, SelfAttention1d, SkipBlock, FourierFeatures, Downsample1d, Upsample1d)
+from .blocks import (ResConvBlock, SelfAttention1d, SkipBlock, FourierFeatures, Downsample1d, Upsample1d,
+                     Downsample1d_2, Upsample1d_2, fold_down_weight, fold_up_weight)
 from .pqmf import CachedPQMF
 
 GN_EPS = 1e-5
@@ -207,6 +208,46 @@ class _Plan:
         self.meta[-1].update(L=x.L, c=x.C, bytes=float(self.B) * x.C * (x.L + Lo) * (4 if x.f32 else 2))
         return y
 
+    def shuffle(self, x, factor, to_depth, out=None):
+        """space_to_depth ([C, L] -> [f*C, L/f]) / depth_to_space ([f*C, L] -> [C, L*f]) around a learned resampler."""
+        if to_depth:
+            C, Co, Lo = x.C, x.C * factor, x.L // factor
+        else:
+            C, Co, Lo = x.C // factor, x.C // factor, x.L * factor
+        y = out if out is not None else self.tensor(Co, Lo)
+        self._emit(_lib.OP_SPACE_TO_DEPTH if to_depth else _lib.OP_DEPTH_TO_SPACE,
+                   {"x": ("arena", x.off), "y": ("arena", y.off)}, L=x.L, Cin=C, i0=factor)
+        self.meta[-1].update(L=x.L, c=x.C, bytes=2.0 * self.B * x.C * x.L * (4 if x.f32 else 2))
+        return y
+
+    def resample_down(self, mod, key, x):
+        """Downsample1d (FIR) or Downsample1d_2 (reference blocks/blocks.py:214-226: Conv1d k=2f+1, stride f, padding f,
+        run as space_to_depth + 3-tap conv with host-folded weights)."""
+        if isinstance(mod, Downsample1d):
+            return self.fir(x, key + "kernel", mod.kernel, up=False)
+        f = mod.stride[0]
+        folded = self.shuffle(x, f, True) if f > 1 else x
+        d, _ = self.conv(folded, key + f"fold{f}", fold_down_weight(mod.weight.detach().float().cpu(), f), mod.bias,
+                         mod.out_channels)
+        if f > 1:
+            self.free(folded)
+        return d
+
+    def resample_up(self, mod, key, u, out):
+        """Upsample1d (FIR) or Upsample1d_2 (blocks/blocks.py:229-255: ConvTranspose1d k=2f, stride f; factor 1: Conv1d
+        k=3), run as a 3-tap conv producing f phases + depth_to_space."""
+        if isinstance(mod, Upsample1d):
+            self.fir(u, key + "kernel", mod.kernel, up=True, out=out)
+            return
+        if isinstance(mod, nn.Conv1d):                         # factor == 1
+            self.conv(u, key + "k3", mod.weight, mod.bias, mod.out_channels, out=out)
+            return
+        f = mod.stride[0]
+        w3, b3 = fold_up_weight(mod.weight.detach().float().cpu(), None if mod.bias is None else mod.bias.detach().float().cpu(), f)
+        z, _ = self.conv(u, key + f"fold{f}", w3, b3, f * mod.out_channels)
+        self.shuffle(z, f, False, out=out)
+        self.free(z)
+
     # ---- module lowering -----------------------------------------------------------------
     def res_block(self, blk, key, x, out=None, stats=False):
         """ResConvBlock (reference blocks/blocks.py:66-76,14-15).  Does not free x."""
@@ -274,7 +315,7 @@ class _Plan:
         m = skip.main
         c_prev = cat.C // 2
         x = self.half(cat, 1, c_prev)
-        d = self.fir(x, key + "0.kernel", m[0].kernel, up=False)
+        d = self.resample_down(m[0], key + "0.", x)
         inner = m[7]
         keys = [f"{key}{j}." for j in range(15)]
         if isinstance(inner, SkipBlock):
@@ -286,7 +327,7 @@ class _Plan:
         else:
             h = self.block_chain(list(m[1:7]), keys[1:7], d)
         u = self.block_chain(list(m[8:14]), keys[8:14], h)
-        self.fir(u, key + "14.kernel", m[14].kernel, up=True, out=self.half(cat, 0, c_prev))
+        self.resample_up(m[14], key + "14.", u, self.half(cat, 0, c_prev))
         self.free(u)
 
     def _build(self):
@@ -406,15 +447,14 @@ class DiffusionAttnUnet1D(nn.Module):
         conv_bias=True,
     ):
         super().__init__()
-        if learned_resample:
-            raise NotImplementedError("learned_resample=True (Downsample1d_2/Upsample1d_2) is not on the MI355X hot path yet")
-        if kernel_size != 5:
-            raise NotImplementedError("libadk convolution kernels are built for kernel_size=5")
+        if kernel_size not in (3, 5, 7):
+            raise NotImplementedError("libadk convolution kernels are built for kernel_size 3, 5 and 7")
         if depth < 2:
             raise ValueError("depth must be >= 2 (the reference's depth-1 net has mismatched channels)")
         self.io_channels, self.depth, self.n_attn_layers = io_channels, depth, n_attn_layers
         self.c_mults = list(c_mults)
         self.pqmf_bands, self.kernel_size = pqmf_bands, kernel_size
+        self.learned_resample, self.strides = learned_resample, list(strides)
         self.cond_dim, self.cond_noise_aug = cond_dim, cond_noise_aug
         if cond_noise_aug:                 # reference :77-78 (Sobol level per sample when no cond_aug_scale is given)
             self.rng = torch.quasirandom.SobolEngine(1, scramble=True)
@@ -430,14 +470,17 @@ class DiffusionAttnUnet1D(nn.Module):
             c = c_mults[i - 1]
             if i > 1:
                 c_prev = c_mults[i - 2]
+                stride = strides[i - 1]
                 add_attn = i >= attn_layer and n_attn_layers > 0
 
                 def attn(ch):
                     return SelfAttention1d(ch, ch // 32) if add_attn else nn.Identity()
-                mods = [Downsample1d("cubic"), conv_block(c_prev, c, c)]
+                mods = [Downsample1d_2(c_prev, c_prev, stride) if learned_resample else Downsample1d("cubic"),
+                        conv_block(c_prev, c, c)]
                 mods += [attn(c), conv_block(c, c, c), attn(c), conv_block(c, c, c), attn(c), block]
                 mods += [conv_block(c * 2 if i != depth else c, c, c), attn(c), conv_block(c, c, c), attn(c)]
-                mods += [conv_block(c, c, c_prev), attn(c_prev), Upsample1d(kernel="cubic")]
+                mods += [conv_block(c, c, c_prev), attn(c_prev),
+                         Upsample1d_2(c_prev, c_prev, stride) if learned_resample else Upsample1d(kernel="cubic")]
                 block = SkipBlock(*mods)
             else:
                 cond_embed_dim = 32 if cond_noise_aug else 16
@@ -483,6 +526,17 @@ class DiffusionAttnUnet1D(nn.Module):
         if T % self.pqmf_bands:
             raise ValueError(f"T={T} is not a multiple of pqmf_bands={self.pqmf_bands}")
         L = T // self.pqmf_bands
+        if self.learned_resample:
+            # strided conv / transposed conv pairs (blocks/blocks.py:214-255) only restore the length when every
+            # level's input is a multiple of its stride; the reference then fails in SkipBlock's torch.cat
+            lin = L
+            for i in range(2, self.depth + 1):
+                f = self.strides[i - 1]
+                if lin % f or lin // f < 1:
+                    raise RuntimeError(f"level {i}: length {lin} is not a multiple of its stride {f} "
+                                       "(the reference fails in torch.cat with mismatched lengths)")
+                lin //= f
+            return
         if L % (1 << (self.depth - 1)):
             raise ValueError(f"length {L} must be divisible by 2^(depth-1)={1 << (self.depth - 1)}")
         for i in range(2, self.depth + 1):

@@ -110,7 +110,12 @@ def _level(sd, cfg, p, i, x, taps):
     """One SkipBlock at level i>1 (diffusion_decoder.py:97-121); p = prefix of its .main"""
     depth = cfg["depth"]
     attn = i in attn_levels(cfg)
-    h = downsample_fir(x, sd[p + "0.kernel"])
+    learned = cfg["learned_resample"]
+    f = cfg["strides"][i - 1]
+    if learned:     # Downsample1d_2 (blocks/blocks.py:214-226): Conv1d(k = 2f+1, stride f, padding f)
+        h = F.conv1d(x, sd[p + "0.weight"], sd[p + "0.bias"], stride=f, padding=f)
+    else:
+        h = downsample_fir(x, sd[p + "0.kernel"])
     for j in (1, 3, 5):
         h = res_conv_block(sd, f"{p}{j}.", h)
         if attn:
@@ -121,14 +126,18 @@ def _level(sd, cfg, p, i, x, taps):
         h = res_conv_block(sd, f"{p}{j}.", h)
         if attn:
             h = self_attention(sd, f"{p}{j + 1}.", h)
-    h = upsample_fir(h, sd[p + "14.kernel"])
+    if not learned:
+        h = upsample_fir(h, sd[p + "14.kernel"])
+    elif f == 1:    # Upsample1d_2 (blocks/blocks.py:229-255): factor 1 is a plain k=3 conv
+        h = F.conv1d(h, sd[p + "14.weight"], sd[p + "14.bias"], padding=1)
+    else:           # ConvTranspose1d(k = 2f, stride f, padding f//2 + f%2, output_padding f%2)
+        h = F.conv_transpose1d(h, sd[p + "14.weight"], sd[p + "14.bias"], stride=f,
+                               padding=f // 2 + f % 2, output_padding=f % 2)
     return torch.cat([h, x], dim=1)                    # blocks.py:151-152: main first
 
 
 def net_forward(sd, cfg, h):
     """self.net(...) (diffusion_decoder.py:124-132)."""
-    if cfg["learned_resample"]:
-        raise NotImplementedError("learned_resample=True is outside the hot path (SURVEY 8 f2)")
     for j in (0, 1, 2):
         h = res_conv_block(sd, f"net.{j}.", h)
     if cfg["depth"] > 1:

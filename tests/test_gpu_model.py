@@ -17,7 +17,9 @@ from conftest import load_npz, sub_sd, rel_err, snr_db
 
 pytestmark = pytest.mark.gpu
 
-TINY = ["tiny_d3.npz", "tiny_d5.npz", "tiny_d3_pqmf4.npz", "tiny_d4_noattn_nobias.npz"]
+TINY = ["tiny_d3.npz", "tiny_d5.npz", "tiny_d3_pqmf4.npz", "tiny_d4_noattn_nobias.npz",
+        # learned resamplers (strides 2/4/1 and 3/8), kernel_size 7 and 3
+        "tiny_learned_k7.npz", "tiny_learned_s3_k3.npz", "tiny_d3_k7_fir.npz"]
 
 
 def build(z, dev):
@@ -51,7 +53,9 @@ def test_tiny_forward_bf16(name):
     y = m(torch.from_numpy(z["x"]).to(dev), torch.from_numpy(z["t"]).to(dev))
     ref = torch.from_numpy(z["y"])
     assert rel_err(y, ref) <= 5e-2
-    assert float((y.cpu().double() - ref.double()).norm() / ref.double().norm()) <= 2e-2
+    # learned-resampler models round two more bf16 tensors per level (phase-folded conv output) and, at C = 32..64
+    # with k = 3, average over short dot products: 2.6e-2 measured on tiny_learned_s3_k3 (fp32 path: <= 1e-4)
+    assert float((y.cpu().double() - ref.double()).norm() / ref.double().norm()) <= (3e-2 if "learned" in name else 2e-2)
 
 
 @pytest.mark.parametrize("name", TINY)

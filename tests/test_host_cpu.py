@@ -68,7 +68,8 @@ def test_full_model_init_matches_reference_digest():
     assert kinds.count(_lib.OP_CONV) == 259          # 168 k=5 + 19 skips + 72 qkv/out projections
 
 
-@pytest.mark.parametrize("name", ["tiny_d3.npz", "tiny_d5.npz", "tiny_d3_pqmf4.npz", "tiny_d4_noattn_nobias.npz"])
+@pytest.mark.parametrize("name", ["tiny_d3.npz", "tiny_d5.npz", "tiny_d3_pqmf4.npz", "tiny_d4_noattn_nobias.npz",
+                                  "tiny_learned_k7.npz", "tiny_learned_s3_k3.npz", "tiny_d3_k7_fir.npz", "tiny_d3_cond.npz"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_tiny_models_load_and_plan(name, dtype):
     z = load_npz(name)
@@ -98,7 +99,11 @@ def test_ctor_errors_mirror_reference():
     with pytest.raises(ZeroDivisionError):          # attention on C < 32 (blocks/blocks.py:106)
         A.DiffusionAttnUnet1D(depth=3, c_mults=[16, 16, 16], n_attn_layers=1)
     with pytest.raises(NotImplementedError):
-        A.DiffusionAttnUnet1D(learned_resample=True)
+        A.DiffusionAttnUnet1D(depth=3, c_mults=[32, 32, 64], kernel_size=9)
+    lr = A.DiffusionAttnUnet1D(depth=3, c_mults=[32, 32, 64], n_attn_layers=0, learned_resample=True, strides=[1, 4, 2])
+    with pytest.raises(RuntimeError):
+        lr.check_input(torch.zeros(1, 2, 1026))       # not a multiple of the level strides
+    lr.check_input(torch.zeros(1, 2, 1024))
     m = A.DiffusionAttnUnet1D(depth=3, c_mults=[32, 32, 64], n_attn_layers=1)
     with pytest.raises(RuntimeError):
         m.check_input(torch.zeros(1, 2, 8))
@@ -162,3 +167,24 @@ def test_crash_schedule_table_matches_oracle():
         t, al, si = S.schedule(steps, crash=True)
         assert torch.equal(tab[:, 0], t) and torch.equal(tab[:, 1], al) and torch.equal(tab[:, 2], si)
         assert float(tab[0, 0]) == 1.0 and bool((tab[1:, 0] < tab[:-1, 0]).all())
+
+
+def test_learned_resampler_folds_match_torch():
+    """Host logic of SURVEY 8(f2): Downsample1d_2 / Upsample1d_2 (blocks/blocks.py:214-255) as phase fold + 3-tap conv."""
+    import torch.nn.functional as F
+    from audio_diffusion_amd.blocks import fold_down_weight, fold_up_weight
+    torch.manual_seed(0)
+    for f in (1, 2, 3, 4, 8):
+        C, Co, L = 6, 5, 24 * f
+        x = torch.randn(2, C, L, dtype=torch.float64)
+        w, b = torch.randn(Co, C, 2 * f + 1, dtype=torch.float64), torch.randn(Co, dtype=torch.float64)
+        ref = F.conv1d(x, w, b, stride=f, padding=f)
+        xf = x.view(2, C, L // f, f).permute(0, 3, 1, 2).reshape(2, f * C, L // f)            # space_to_depth
+        assert torch.allclose(F.conv1d(xf, fold_down_weight(w, f), b, padding=1), ref, atol=1e-12)
+        if f > 1:
+            wt = torch.randn(C, Co, 2 * f, dtype=torch.float64)
+            ref = F.conv_transpose1d(x, wt, b, stride=f, padding=f // 2 + f % 2, output_padding=f % 2)
+            w3, b3 = fold_up_weight(wt, b, f)
+            z = F.conv1d(x, w3, b3, padding=1)
+            got = z.view(2, f, Co, L).permute(0, 2, 3, 1).reshape(2, Co, L * f)                # depth_to_space
+            assert got.shape == ref.shape and torch.allclose(got, ref, atol=1e-12)

@@ -96,7 +96,9 @@ def test_pqmf_design_and_transform(golden_pqmf, ch, att, M):
     assert float(err.pow(2).mean().sqrt() / x.pow(2).mean().sqrt()) < 10 ** (-40 / 20)
 
 
-TINY = ["tiny_d3.npz", "tiny_d5.npz", "tiny_d3_pqmf4.npz", "tiny_d4_noattn_nobias.npz"]
+TINY = ["tiny_d3.npz", "tiny_d5.npz", "tiny_d3_pqmf4.npz", "tiny_d4_noattn_nobias.npz",
+        # learned resamplers (strides 2/4/1 and 3/8), kernel_size 7 and 3
+        "tiny_learned_k7.npz", "tiny_learned_s3_k3.npz", "tiny_d3_k7_fir.npz"]
 
 
 @pytest.mark.parametrize("name", TINY)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate golden vectors by IMPORTING the reference (this container only).
 
-Run:  python tools/make_goldens.py [--tier B T C F] [--ref /root/reference]
+Run:  python tools/make_goldens.py [--tier B T C R F] [--ref /root/reference]
 Writes small fixtures (inputs + expected outputs, never source text) to tests/golden/.
 
 The reference's hot path is Python; three of its imports are unavailable or have drifted in this
@@ -235,6 +235,18 @@ def run_cond_golden(name, Model, sampling, kwargs, x_shape, cond_len, seed, aug_
         cfg=np.bytes_(json.dumps(dict(kwargs)).encode()), **sd_arrays(m.state_dict()))
 
 
+def tier_learned(Model, sampling):
+    print("tier R: learned resamplers + kernel_size 7 / 3 (SURVEY 8 f2)")
+    run_model_golden("tiny_learned_k7.npz", Model, sampling,
+                     dict(depth=4, c_mults=[32, 32, 64, 64], n_attn_layers=1, learned_resample=True,
+                          strides=[9, 2, 4, 1], kernel_size=7), (2, 2, 1024), seed=50, steps=4)
+    run_model_golden("tiny_learned_s3_k3.npz", Model, sampling,
+                     dict(depth=3, c_mults=[32, 64, 64], n_attn_layers=0, learned_resample=True,
+                          strides=[1, 3, 8], kernel_size=3, io_channels=1), (3, 1, 1536), seed=51, steps=4)
+    run_model_golden("tiny_d3_k7_fir.npz", Model, sampling,
+                     dict(depth=3, c_mults=[32, 32, 64], n_attn_layers=1, kernel_size=7), (2, 2, 512), seed=52, steps=4)
+
+
 def tier_cond(Model, sampling):
     print("tier C: conditioning path (SURVEY 8 f1)")
     run_cond_golden("tiny_d3_cond.npz", Model, sampling,
@@ -289,7 +301,7 @@ def tier_full(Model, sampling):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--tier", nargs="+", default=["B", "T", "C", "F"])
+    ap.add_argument("--tier", nargs="+", default=["B", "T", "C", "R", "F"])
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     P, Model, sampling, blocks = import_reference(a.ref)
@@ -299,6 +311,8 @@ def main():
         tier_tiny(Model, sampling)
     if "C" in a.tier:
         tier_cond(Model, sampling)
+    if "R" in a.tier:
+        tier_learned(Model, sampling)
     if "F" in a.tier:
         tier_full(Model, sampling)
 

@@ -7,13 +7,15 @@ Public surface (same names as the reference):
     sample_diffae                            diffusion/inference.py:14-57 (encode / decode DDIM variant)
     audio_to_int16                           train_uncond.py:182-187 (rearrange + clamp + int16 output stage)
     CachedPQMF                               diffusion/pqmf.py:236-302 (design + forward/inverse on libadk)
+    AudioDenoiserModel, Denoiser             decoders/diffusion_decoder.py:261-337 (k-diffusion denoiser family)
 Compute runs exclusively in libadk.so (hand-written gfx950 HIP kernels, C ABI in include/adk.h).
 """
 from .unet import DiffusionAttnUnet1D
 from .sampling import (sample, sample_crash, sample_diffae, audio_to_int16, get_alphas_sigmas, alpha_sigma_to_t,
                        get_crash_schedule, step_coefficients)
 from .pqmf import CachedPQMF
-from . import _lib
+from .kdiffusion import AudioDenoiserModel, Denoiser
+from . import _lib, blocks
 
 __all__ = ["DiffusionAttnUnet1D", "sample", "sample_crash", "sample_diffae", "audio_to_int16", "get_alphas_sigmas",
-           "alpha_sigma_to_t", "get_crash_schedule", "step_coefficients", "CachedPQMF"]
+           "alpha_sigma_to_t", "get_crash_schedule", "step_coefficients", "CachedPQMF", "AudioDenoiserModel", "Denoiser"]

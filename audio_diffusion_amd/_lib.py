@@ -15,8 +15,9 @@ ADK_F32, ADK_BF16 = 0, 1
 OP_CONV, OP_GN_APPLY, OP_GN_STATS, OP_FIR_DOWN, OP_FIR_UP, OP_ATTN = 1, 2, 3, 4, 5, 6
 OP_PACK_INPUT, OP_UNPACK_OUTPUT, OP_PQMF_ANALYSIS, OP_PQMF_SYNTHESIS = 7, 8, 9, 10
 OP_DDIM_UPDATE, OP_STEP_ADVANCE, OP_AUDIO_TO_INT16, OP_SPACE_TO_DEPTH, OP_DEPTH_TO_SPACE = 11, 12, 13, 14, 15
+OP_LINEAR, OP_FOURIER = 16, 17
 
-FLAG_GELU, FLAG_OUT_F32, FLAG_NOISE = 1, 2, 4
+FLAG_GELU, FLAG_OUT_F32, FLAG_NOISE, FLAG_ADA, FLAG_LOG, FLAG_NO_EMBED = 1, 2, 4, 8, 16, 32
 
 
 class AdkOp(C.Structure):
@@ -40,6 +41,8 @@ EXPORTS = [
     "adk_conv1d", "adk_gn_apply", "adk_gn_stats", "adk_fir_down2", "adk_fir_up2", "adk_attn1d",
     "adk_pack_input", "adk_pack_input_cond", "adk_unpack_output", "adk_pqmf_analysis", "adk_pqmf_synthesis",
     "adk_ddim_update", "adk_step_advance", "adk_audio_to_int16", "adk_space_to_depth", "adk_depth_to_space",
+    "adk_attn1d_hd", "adk_adagn_apply", "adk_linear", "adk_fourier_features", "adk_pack_input_plain",
+    "adk_unpack_output_scaled",
 ]
 
 _lib = None
@@ -86,6 +89,12 @@ def load():
     lib.adk_audio_to_int16.argtypes = [i32, i32, i32, vp, vp, vp]
     lib.adk_space_to_depth.argtypes = [i32, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.adk_depth_to_space.argtypes = [i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.adk_attn1d_hd.argtypes = [i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.adk_adagn_apply.argtypes = [i32, u32, i32, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp, i32, vp, vp]
+    lib.adk_linear.argtypes = [u32, i32, i32, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp]
+    lib.adk_fourier_features.argtypes = [u32, i32, i32, vp, vp, vp, i32, vp]
+    lib.adk_pack_input_plain.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp, vp]
+    lib.adk_unpack_output_scaled.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         if name not in ("adk_last_error",):
             getattr(lib, name).restype = C.c_int

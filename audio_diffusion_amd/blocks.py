@@ -162,3 +162,116 @@ def fold_up_weight(wt, bias, factor):
             out[s, :, :, 1], out[s, :, :, 2] = hi, lo
     b = None if bias is None else bias.repeat(f)
     return out.reshape(f * co, c, 3), b
+
+
+# ---- k-diffusion ("audio_v1") family: parameter containers of AudioDenoiserModel ---------------------------------
+class AdaGN(_NoCompute):
+    """key: mapper.{weight,bias} = Linear(feats_in, 2*c_out) (blocks/blocks.py:53-59)."""
+
+    def __init__(self, feats_in, c_out, num_groups, eps=1e-5, cond_key="cond"):
+        super().__init__()
+        self.num_groups, self.eps, self.cond_key, self.c_out = num_groups, eps, cond_key, c_out
+        self.mapper = nn.Linear(feats_in, c_out * 2)
+
+
+class ResModConvBlock(_NoCompute):
+    """keys: main.{0,4}.mapper.*, main.{2,6}.{weight,bias}, skip.weight (blocks/blocks.py:89-101):
+    AdaGN -> GELU -> Conv1d(3) -> AdaGN -> GELU -> Conv1d(3), plus the (1x1 or identity) skip."""
+
+    def __init__(self, feats_in, c_in, c_mid, c_out, group_size=32, dropout_rate=0.):
+        super().__init__()
+        skip = None if c_in == c_out else nn.Conv1d(c_in, c_out, 1, bias=False)      # built first, like the reference
+        self.main = nn.Sequential(
+            AdaGN(feats_in, c_in, max(1, c_in // group_size)),
+            nn.GELU(),
+            nn.Conv1d(c_in, c_mid, 3, padding=1),
+            nn.Dropout(dropout_rate, inplace=True),
+            AdaGN(feats_in, c_mid, max(1, c_mid // group_size)),
+            nn.GELU(),
+            nn.Conv1d(c_mid, c_out, 3, padding=1),
+            nn.Dropout(dropout_rate, inplace=True),
+        )
+        self.skip = skip if skip is not None else nn.Identity()
+        self.c_in, self.c_mid, self.c_out = c_in, c_mid, c_out
+
+
+class SelfAttentionMod1d(_NoCompute):
+    """keys: norm_in.mapper.*, qkv_proj.*, out_proj.* (blocks/blocks.py:124-132)."""
+
+    def __init__(self, c_in, n_head, norm, dropout_rate=0.):
+        super().__init__()
+        assert c_in % n_head == 0
+        if c_in // n_head not in (32, 64):
+            raise NotImplementedError(f"libadk attention supports head dims 32 and 64, got {c_in // n_head}")
+        self.norm_in = norm(c_in)
+        self.n_head = n_head
+        self.qkv_proj = nn.Conv1d(c_in, c_in * 3, 1)
+        self.out_proj = nn.Conv1d(c_in, c_in, 1)
+        self.c_in = c_in
+
+
+def _mod_layers(n_layers, feats_in, c_in, c_mid, c_out, group_size, head_size, dropout_rate, self_attn):
+    mods = []
+    for i in range(n_layers):
+        ci = c_in if i == 0 else c_mid
+        co = c_mid if i < n_layers - 1 else c_out
+        mods.append(ResModConvBlock(feats_in, ci, c_mid, co, group_size, dropout_rate))
+        if self_attn:
+            mods.append(SelfAttentionMod1d(co, max(1, co // head_size),
+                                           lambda c, co=co: AdaGN(feats_in, c, max(1, co // group_size)), dropout_rate))
+    return mods
+
+
+class DBlock(nn.Sequential):
+    """[Downsample1d_2] + n_layers x (ResModConvBlock [+ SelfAttentionMod1d]) (blocks/blocks.py:260-270)."""
+
+    def __init__(self, n_layers, feats_in, c_in, c_mid, c_out, group_size=32, head_size=64, dropout_rate=0.,
+                 downsample_ratio=1, self_attn=False):
+        mods = [Downsample1d_2(c_in, c_in, downsample_ratio)] if downsample_ratio > 1 else []
+        mods += _mod_layers(n_layers, feats_in, c_in, c_mid, c_out, group_size, head_size, dropout_rate, self_attn)
+        super().__init__(*mods)
+        self.ratio = downsample_ratio
+
+    def forward(self, *a, **k):
+        raise RuntimeError("DBlock is a parameter container; run it through AudioDenoiserModel")
+
+
+class UBlock(nn.Sequential):
+    """n_layers x (ResModConvBlock [+ SelfAttentionMod1d]) + [Upsample1d_2]; input = cat([x, skip]) (blocks.py:273-290)."""
+
+    def __init__(self, n_layers, feats_in, c_in, c_mid, c_out, group_size=32, head_size=64, dropout_rate=0.,
+                 upsample_ratio=1, self_attn=False):
+        mods = _mod_layers(n_layers, feats_in, c_in, c_mid, c_out, group_size, head_size, dropout_rate, self_attn)
+        if upsample_ratio > 1:
+            mods.append(Upsample1d_2(c_out, c_out, upsample_ratio))
+        super().__init__(*mods)
+        self.ratio = upsample_ratio
+
+    def forward(self, *a, **k):
+        raise RuntimeError("UBlock is a parameter container; run it through AudioDenoiserModel")
+
+
+class MappingNet(nn.Sequential):
+    """keys: {0,2}.{weight,bias}; orthogonal init of the Linear weights (blocks/blocks.py:292-301)."""
+
+    def __init__(self, feats_in, feats_out, n_layers=2):
+        layers = []
+        for i in range(n_layers):
+            layers.append(nn.Linear(feats_in if i == 0 else feats_out, feats_out))
+            layers.append(nn.GELU())
+        super().__init__(*layers)
+        for layer in self:
+            if isinstance(layer, nn.Linear):
+                nn.init.orthogonal_(layer.weight)
+
+    def forward(self, *a, **k):
+        raise RuntimeError("MappingNet is a parameter container; run it through AudioDenoiserModel")
+
+
+class UNet(_NoCompute):
+    """keys: d_blocks.N.*, u_blocks.N.* (deepest first) (blocks/blocks.py:303-316)."""
+
+    def __init__(self, d_blocks, u_blocks):
+        super().__init__()
+        self.d_blocks = nn.ModuleList(d_blocks)
+        self.u_blocks = nn.ModuleList(u_blocks)

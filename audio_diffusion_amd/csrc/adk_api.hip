@@ -21,6 +21,8 @@ int launch_ddim_update(const adk_op& op, hipStream_t st);
 int launch_step_advance(const adk_op& op, hipStream_t st);
 int launch_audio_to_int16(const adk_op& op, hipStream_t st);
 int launch_phase_shuffle(const adk_op& op, hipStream_t st, bool to_depth);
+int launch_linear(const adk_op& op, hipStream_t st);
+int launch_fourier(const adk_op& op, hipStream_t st);
 
 static thread_local char g_err[512] = "";
 
@@ -68,6 +70,15 @@ static int validate(const adk_op& o)
         REQUIRE(o.Cin >= 1 && o.x && o.y && o.gamma && o.beta, "gn_apply: null tensor / C=%d", o.Cin);
         REQUIRE(o.partials_in && o.n_partials_in >= 1, "gn_apply: needs input partials");
         REQUIRE(o.f0 > 0.f, "gn_apply: eps=%g", (double)o.f0);
+        if (o.i1 > 1) {                          // GroupNorm(G, C): groups of whole planes, statistics from GN_STATS
+            const int cb = cb_of(o.dtype);
+            REQUIRE(o.Cin % o.i1 == 0 && (o.Cin / o.i1) % cb == 0,
+                    "gn_apply: %d groups of C=%d are not whole %d-channel planes", o.i1, o.Cin, cb);
+            REQUIRE(o.n_partials_in == gn_partials_count(o.dtype, o.Cin, o.L),
+                    "gn_apply: grouped statistics must come from gn_stats (%d partials per sample, got %d)",
+                    gn_partials_count(o.dtype, o.Cin, o.L), o.n_partials_in);
+        }
+        if (o.flags & ADK_FLAG_ADA) REQUIRE(o.i0 >= o.Cin, "gn_apply: AdaGN row stride %d < C=%d", o.i0, o.Cin);
         return ADK_OK;
     case ADK_OP_GN_STATS:
         if ((rc = check_geo(o, "gn_stats"))) return rc;
@@ -90,18 +101,31 @@ static int validate(const adk_op& o)
     }
     case ADK_OP_ATTN:
         if ((rc = check_geo(o, "attn1d"))) return rc;
-        REQUIRE(o.Cin >= 32 && o.Cin % 32 == 0, "attn1d: C=%d must be a multiple of the head dim 32", o.Cin);
+        REQUIRE(o.i0 == 0 || o.i0 == 32 || o.i0 == 64, "attn1d: head dim %d unsupported (32 or 64)", o.i0);
+        REQUIRE(o.Cin >= 32 && o.Cin % (o.i0 ? o.i0 : 32) == 0, "attn1d: C=%d must be a multiple of the head dim %d", o.Cin,
+                o.i0 ? o.i0 : 32);
         REQUIRE(o.x && o.y, "attn1d: null tensor");
         return ADK_OK;
     case ADK_OP_PACK_INPUT:
         if ((rc = check_geo(o, "pack_input"))) return rc;
-        REQUIRE(o.Cin >= 1 && o.x && o.w && o.y && o.aux0, "pack_input: null tensor");
+        if (o.flags & ADK_FLAG_NO_EMBED) REQUIRE(o.Cin >= 1 && o.x && o.y && !o.gamma, "pack_input: null tensor");
+        else REQUIRE(o.Cin >= 1 && o.x && o.w && o.y && o.aux0, "pack_input: null tensor");
         REQUIRE(!o.residual || (o.Cout >= 1 && o.i1 >= 1), "pack_input: cond needs Cc >= 1 and Lc >= 1 (got %d, %d)", o.Cout, o.i1);
         REQUIRE(!o.gamma || o.residual, "pack_input: noise-aug levels without a cond tensor");
         return ADK_OK;
     case ADK_OP_UNPACK_OUTPUT:
         if ((rc = check_geo(o, "unpack_output"))) return rc;
         REQUIRE(o.Cin >= 1 && o.x && o.y, "unpack_output: null tensor");
+        REQUIRE(!o.gamma || (o.beta && o.residual), "unpack_output: c_out needs c_skip and the unscaled input");
+        return ADK_OK;
+    case ADK_OP_LINEAR:
+        REQUIRE(o.B >= 1 && o.B <= 65535 && o.Cin >= 1 && o.Cout >= 1 && o.x && o.w && o.y, "linear: bad arguments");
+        REQUIRE(o.i0 >= o.Cin && o.i2 >= o.Cout && (!o.residual || o.i1 >= o.Cout), "linear: row strides (%d, %d, %d) "
+                "smaller than the rows (%d, %d)", o.i0, o.i1, o.i2, o.Cin, o.Cout);
+        return ADK_OK;
+    case ADK_OP_FOURIER:
+        REQUIRE(o.B >= 1 && o.B <= 65535 && o.Cout >= 2 && o.Cout % 2 == 0 && o.x && o.w && o.y, "fourier: bad arguments");
+        REQUIRE(o.i2 >= o.Cout, "fourier: row stride %d < %d features", o.i2, o.Cout);
         return ADK_OK;
     case ADK_OP_PQMF_ANALYSIS:
     case ADK_OP_PQMF_SYNTHESIS: {
@@ -162,6 +186,8 @@ static int dispatch(const adk_op& o, hipStream_t st)
     case ADK_OP_AUDIO_TO_INT16: return launch_audio_to_int16(o, st);
     case ADK_OP_SPACE_TO_DEPTH: return launch_phase_shuffle(o, st, true);
     case ADK_OP_DEPTH_TO_SPACE: return launch_phase_shuffle(o, st, false);
+    case ADK_OP_LINEAR: return launch_linear(o, st);
+    case ADK_OP_FOURIER: return launch_fourier(o, st);
     }
     return ADK_EINVAL;
 }
@@ -278,6 +304,57 @@ int adk_attn1d(int dtype, int B, int L, int P, int C, const void* qkv, void* y, 
 {
     adk_op o = zero_op(ADK_OP_ATTN, dtype);
     o.B = B; o.L = L; o.P = P; o.Cin = C; o.x = qkv; o.y = y;
+    return adk_run_plan(&o, 1, stream);
+}
+
+int adk_attn1d_hd(int dtype, int B, int L, int P, int C, int head_dim, const void* qkv, void* y, void* stream)
+{
+    adk_op o = zero_op(ADK_OP_ATTN, dtype);
+    o.B = B; o.L = L; o.P = P; o.Cin = C; o.i0 = head_dim; o.x = qkv; o.y = y;
+    return adk_run_plan(&o, 1, stream);
+}
+
+int adk_adagn_apply(int dtype, uint32_t flags, int B, int L, int P, int C, int groups, float eps,
+                    const void* x, const float* partials_in, int n_partials_in,
+                    const float* weight, const float* bias, int row_stride, void* y, void* stream)
+{
+    adk_op o = zero_op(ADK_OP_GN_APPLY, dtype);
+    o.flags = flags | ADK_FLAG_ADA; o.B = B; o.L = L; o.P = P; o.Cin = C; o.Cout = C; o.f0 = eps;
+    o.i0 = row_stride; o.i1 = groups;
+    o.x = x; o.partials_in = partials_in; o.n_partials_in = n_partials_in; o.gamma = weight; o.beta = bias; o.y = y;
+    return adk_run_plan(&o, 1, stream);
+}
+
+int adk_linear(uint32_t flags, int B, int Cin, int Cout, const float* x, int x_stride, const float* w, const float* bias,
+               const float* residual, int res_stride, float* y, int y_stride, void* stream)
+{
+    adk_op o = zero_op(ADK_OP_LINEAR, ADK_F32);
+    o.flags = flags; o.B = B; o.Cin = Cin; o.Cout = Cout; o.x = x; o.i0 = x_stride; o.w = w; o.bias = bias;
+    o.residual = residual; o.i1 = res_stride; o.y = y; o.i2 = y_stride;
+    return adk_run_plan(&o, 1, stream);
+}
+
+int adk_fourier_features(uint32_t flags, int B, int F, const float* sigma, const float* w, float* y, int y_stride, void* stream)
+{
+    adk_op o = zero_op(ADK_OP_FOURIER, ADK_F32);
+    o.flags = flags; o.B = B; o.Cout = F; o.x = sigma; o.w = w; o.y = y; o.i2 = y_stride;
+    return adk_run_plan(&o, 1, stream);
+}
+
+int adk_pack_input_plain(int dtype, int B, int L, int P, int Cx, const float* x, const float* x_scale,
+                         const float* cond, int Cc, int Lc, void* y, void* stream)
+{
+    adk_op o = zero_op(ADK_OP_PACK_INPUT, dtype);
+    o.flags = ADK_FLAG_NO_EMBED; o.B = B; o.L = L; o.P = P; o.Cin = Cx; o.x = x; o.beta = x_scale; o.y = y;
+    o.residual = cond; o.Cout = Cc; o.i1 = Lc;
+    return adk_run_plan(&o, 1, stream);
+}
+
+int adk_unpack_output_scaled(int B, int L, int P, int C, const float* x, const float* c_out, const float* c_skip,
+                             const float* x_in, float* y, void* stream)
+{
+    adk_op o = zero_op(ADK_OP_UNPACK_OUTPUT, ADK_F32);
+    o.B = B; o.L = L; o.P = P; o.Cin = C; o.x = x; o.gamma = c_out; o.beta = c_skip; o.residual = x_in; o.y = y;
     return adk_run_plan(&o, 1, stream);
 }
 

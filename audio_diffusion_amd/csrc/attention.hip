@@ -1,8 +1,9 @@
-// SelfAttention1d core: y = softmax((q d^-1/4)(k d^-1/4)^T) v, head dim d = 32, flash-style (online
-// softmax, the [s,s] score matrix is never materialised).  Reference blocks/blocks.py:116-121.
+// SelfAttention1d / SelfAttentionMod1d core: y = softmax((q d^-1/4)(k d^-1/4)^T) v, head dim d = 32
+// (DiffusionAttnUnet1D: n_head = C/32) or 64 (AudioDenoiserModel: head_size 64), flash-style (online
+// softmax, the [s,s] score matrix is never materialised).  Reference blocks/blocks.py:116-121, 137-143.
 //
-// Layout: qkv is CPL [B, 3C, L] with channel order (q heads | k heads | v heads); a head's 32 channels
-// are one 64-byte row (bf16) or two (f32), so Q/K/V tiles of a head are contiguous row ranges.
+// Layout: qkv is CPL [B, 3C, L] with channel order (q heads | k heads | v heads); a head's d channels
+// are d/32 64-byte rows (bf16) or d/16 (f32) in consecutive planes, so Q/K/V tiles of a head are row ranges.
 //
 // bf16: attn_mfma_kernel.  One WAVE owns TQ*32 query rows of one (sample, head) and streams that head's
 // K/V in 32-key tiles through a wave-private LDS ring filled by LDS-DMA (3 tiles in flight, counted vmcnt,
@@ -24,9 +25,9 @@ struct AttnArgs {
     int C, heads, ntq;
 };
 
-constexpr int ATT_TQ = 64, ATT_TK = 64, ATT_D = 32;
+constexpr int ATT_TQ = 64, ATT_TK = 64;
 
-template <typename T>
+template <typename T, int ATT_D>
 __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a)
 {
     constexpr int CB = ElemTraits<T>::CB, NV = ElemTraits<T>::NV;
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a)
     const int qi = tq * ATT_TQ + lane;
     const bool qvalid = qi < a.L;
     float q[ATT_D], o[ATT_D];
-    const float qscale = 0.17677669529663687f;     // (32^-1/4)^2
+    const float qscale = ATT_D == 32 ? 0.17677669529663687f : 0.125f;     // (d^-1/4)^2
 #pragma unroll
     for (int pc = 0; pc < PPR; ++pc) {
         float f[NV];
@@ -151,7 +152,7 @@ struct AttnMfmaArgs {
 
 constexpr int ATT_VBUF = 2048;              // one 32-key V tile, linear [key][32] bf16
 
-template <int TQ>
+template <int TQ, int DP>                     // DP = 64-byte planes per head (head dim 32 * DP)
 __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnMfmaArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -162,76 +163,89 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnMfmaArgs a)
     const int qt = item % a.ntq, rest = item / a.ntq, hd = rest % a.heads, b = rest / a.heads;
     const long long srow = (long long)b * a.Lp + a.P;       // first valid row of the sample
     const int last = a.L - 1;
-    const unsigned char* qg = reinterpret_cast<const unsigned char*>(a.qkv) + ((long long)hd * a.M + srow) * 64;
-    const unsigned char* kg = qg + (long long)a.heads * a.M * 64;
-    const unsigned char* vg = kg + (long long)a.heads * a.M * 64;
-    unsigned char* vlds = smem + wave * (2 * ATT_VBUF);     // wave-private double buffer
+    const long long pstride = a.M * 64;                     // bytes between the planes of one head
+    const unsigned char* qg = reinterpret_cast<const unsigned char*>(a.qkv) + ((long long)hd * DP * a.M + srow) * 64;
+    const unsigned char* kg = qg + (long long)a.heads * DP * pstride;
+    const unsigned char* vg = kg + (long long)a.heads * DP * pstride;
+    unsigned char* vlds = smem + wave * (2 * DP * ATT_VBUF);     // wave-private double buffer
 
-    // Q fragments (B operand of S^T = K Q^T): lane (q = l31, h) holds Q[q][16 ks + 8 h .. +7]
-    bf16x8 qf[TQ][2];
+    // Q fragments (B operand of S^T = K Q^T): lane (q = l31, h) holds Q[q][32 p + 16 ks + 8 h .. +7]
+    bf16x8 qf[TQ][DP][2];
 #pragma unroll
     for (int u = 0; u < TQ; ++u) {
         int q = (qt * TQ + u) * 32 + l31;
         q = q > last ? last : q;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            qf[u][ks] = *reinterpret_cast<const bf16x8*>(qg + (long long)q * 64 + (2 * ks + h) * 16);
+        for (int p = 0; p < DP; ++p)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                qf[u][p][ks] = *reinterpret_cast<const bf16x8*>(qg + p * pstride + (long long)q * 64 + (2 * ks + h) * 16);
     }
 
     // One K/V tile = 32 keys.  K goes straight to registers in A-fragment layout (lane (key = l31, h) holds
-    // K[key][16 ks + 8 h .. +7]); V is fetched as whole rows (lane: piece (lane & 3) of row 16 j + (lane >> 2)),
+    // K[key][32 p + 16 ks + 8 h .. +7]); V is fetched as whole rows (lane: piece (lane & 3) of row 16 j + (lane >> 2)),
     // parked in the wave's LDS buffer and gathered back transposed.  Tile kt+1 is in flight while kt computes.
-    struct KvTile { uint4 k0, k1, v0, v1; };
+    struct KvTile { uint4 k[DP][2], v[DP][2]; };
     auto fetch_tile = [&](int kt) -> KvTile {
         KvTile r;
         int key = kt * 32 + l31;
         key = key > last ? last : key;                      // keys past the sample are masked below
-        const unsigned char* kp = kg + (long long)key * 64 + h * 16;
-        r.k0 = *reinterpret_cast<const uint4*>(kp);
-        r.k1 = *reinterpret_cast<const uint4*>(kp + 32);
         int vk0 = kt * 32 + (lane >> 2), vk1 = vk0 + 16;
         vk0 = vk0 > last ? last : vk0;
         vk1 = vk1 > last ? last : vk1;
-        r.v0 = *reinterpret_cast<const uint4*>(vg + (long long)vk0 * 64 + (lane & 3) * 16);
-        r.v1 = *reinterpret_cast<const uint4*>(vg + (long long)vk1 * 64 + (lane & 3) * 16);
+#pragma unroll
+        for (int p = 0; p < DP; ++p) {
+            const unsigned char* kp = kg + p * pstride + (long long)key * 64 + h * 16;
+            r.k[p][0] = *reinterpret_cast<const uint4*>(kp);
+            r.k[p][1] = *reinterpret_cast<const uint4*>(kp + 32);
+            r.v[p][0] = *reinterpret_cast<const uint4*>(vg + p * pstride + (long long)vk0 * 64 + (lane & 3) * 16);
+            r.v[p][1] = *reinterpret_cast<const uint4*>(vg + p * pstride + (long long)vk1 * 64 + (lane & 3) * 16);
+        }
         return r;
     };
 
-    f32x16 o[TQ];
+    f32x16 o[TQ][DP];
     float mrun[TQ], lrun[TQ];
 #pragma unroll
     for (int u = 0; u < TQ; ++u) {
         mrun[u] = -INFINITY; lrun[u] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[u][r] = 0.f;
+        for (int p = 0; p < DP; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[u][p][r] = 0.f;
     }
 
     // V^T gather (ds_read_b64_tr_b16): lane supplies row 16 s + 8 u + 4 h + ((lane & 15) >> 2), d columns
     // 16 ((lane >> 4) & 1) + 4 (lane & 3) .. +3 of the linear [key][32] image; 32 lanes cover 256 contiguous
     // bytes, so the gather is bank-conflict free
     const int voff = (4 * h + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-    const float c = 0.25503486f;                            // log2(e) * 32^-1/2  (q and k each scaled by 32^-1/4)
+    const float c = DP == 1 ? 0.25503486f : 0.18033688f;    // log2(e) * d^-1/2  (q and k each scaled by d^-1/4)
 
     const int nt = (a.L + 31) >> 5;
     KvTile cur = fetch_tile(0);
     for (int kt = 0; kt < nt; ++kt) {
-        unsigned char* vb = vlds + (kt & 1) * ATT_VBUF;
-        *reinterpret_cast<uint4*>(vb + lane * 16) = cur.v0;
-        *reinterpret_cast<uint4*>(vb + 1024 + lane * 16) = cur.v1;
-        union { uint4 q; bf16x8 f; } kf[2];
-        kf[0].q = cur.k0; kf[1].q = cur.k1;
+        unsigned char* vb = vlds + (kt & 1) * (DP * ATT_VBUF);
+        union { uint4 q; bf16x8 f; } kf[DP][2];
+#pragma unroll
+        for (int p = 0; p < DP; ++p) {
+            *reinterpret_cast<uint4*>(vb + p * ATT_VBUF + lane * 16) = cur.v[p][0];
+            *reinterpret_cast<uint4*>(vb + p * ATT_VBUF + 1024 + lane * 16) = cur.v[p][1];
+            kf[p][0].q = cur.k[p][0]; kf[p][1].q = cur.k[p][1];
+        }
         if (kt + 1 < nt) cur = fetch_tile(kt + 1);
 
-        bf16x8 vf[2];
+        bf16x8 vf[DP][2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            union { s16x4 v[2]; bf16x8 f; } cv;
+        for (int p = 0; p < DP; ++p)
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-                cv.v[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(vb + voff + (16 * s + 8 * u) * 64));
-            vf[s] = cv.f;
-        }
+            for (int s = 0; s < 2; ++s) {
+                union { s16x4 v[2]; bf16x8 f; } cv;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    cv.v[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(vb + p * ATT_VBUF + voff + (16 * s + 8 * u) * 64));
+                vf[p][s] = cv.f;
+            }
         const bool ragged = (kt + 1) * 32 > a.L;            // wave-uniform: only the last tile can be partial
 
 #pragma unroll
@@ -239,8 +253,11 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnMfmaArgs a)
             f32x16 st;
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[r] = 0.f;
-            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0].f, qf[u][0], st, 0, 0, 0);
-            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1].f, qf[u][1], st, 0, 0, 0);
+#pragma unroll
+            for (int p = 0; p < DP; ++p) {
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[p][0].f, qf[u][p][0], st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[p][1].f, qf[u][p][1], st, 0, 0, 0);
+            }
             // st[r] = <k_key, q_query>, key = 32 kt + (r & 3) + 8 (r >> 2) + 4 h, query = l31
             if (ragged) {
 #pragma unroll
@@ -261,20 +278,27 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnMfmaArgs a)
                 psum += st[r];
             }
             lrun[u] = lrun[u] * alpha + psum;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[u][r] *= alpha;
+            bf16x8 pf[2];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                union { uint32_t w[4]; bf16x8 f; } pf;
+                union { uint32_t w[4]; bf16x8 f; } pk;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pf.w[e] = pack_bf16x2(st[8 * s + 2 * e], st[8 * s + 2 * e + 1]);
-                o[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s], pf.f, o[u], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) pk.w[e] = pack_bf16x2(st[8 * s + 2 * e], st[8 * s + 2 * e + 1]);
+                pf[s] = pk.f;
+            }
+#pragma unroll
+            for (int p = 0; p < DP; ++p) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[u][p][r] *= alpha;
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    o[u][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[p][s], pf[s], o[u][p], 0, 0, 0);
             }
         }
     }
 
-    // ---- epilogue: o[u][r] = O[query l31][d = (r & 3) + 8 (r >> 2) + 4 h] (unnormalised) ----
-    unsigned char* yb = reinterpret_cast<unsigned char*>(a.y) + ((long long)hd * a.M + srow) * 64;
+    // ---- epilogue: o[u][p][r] = O[query l31][d = 32 p + (r & 3) + 8 (r >> 2) + 4 h] (unnormalised) ----
+    unsigned char* yb = reinterpret_cast<unsigned char*>(a.y) + ((long long)hd * DP * a.M + srow) * 64;
 #pragma unroll
     for (int u = 0; u < TQ; ++u) {
         const float ltot = lrun[u] + __shfl_xor(lrun[u], 32, 64);
@@ -282,44 +306,59 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnMfmaArgs a)
         const int q = (qt * TQ + u) * 32 + l31;
         if (q <= last) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<uint2*>(yb + (long long)q * 64 + (8 * g + 4 * h) * 2) =
-                    make_uint2(pack_bf16x2(o[u][4 * g] * inv, o[u][4 * g + 1] * inv),
-                               pack_bf16x2(o[u][4 * g + 2] * inv, o[u][4 * g + 3] * inv));
+            for (int p = 0; p < DP; ++p)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<uint2*>(yb + p * pstride + (long long)q * 64 + (8 * g + 4 * h) * 2) =
+                        make_uint2(pack_bf16x2(o[u][p][4 * g] * inv, o[u][p][4 * g + 1] * inv),
+                                   pack_bf16x2(o[u][p][4 * g + 2] * inv, o[u][p][4 * g + 3] * inv));
         }
     }
-    if (qt == 0 || qt == a.ntq - 1) {                       // halo rows of this head's plane
+    if (qt == 0 || qt == a.ntq - 1) {                       // halo rows of this head's planes
         const uint4 z = make_uint4(0, 0, 0, 0);
         if (lane < a.P * 4) {
             const int row = lane >> 2, pc = lane & 3;
-            if (qt == 0) *reinterpret_cast<uint4*>(yb + (long long)(row - a.P) * 64 + pc * 16) = z;
-            if (qt == a.ntq - 1) *reinterpret_cast<uint4*>(yb + (long long)(a.L + row) * 64 + pc * 16) = z;
+#pragma unroll
+            for (int p = 0; p < DP; ++p) {
+                if (qt == 0) *reinterpret_cast<uint4*>(yb + p * pstride + (long long)(row - a.P) * 64 + pc * 16) = z;
+                if (qt == a.ntq - 1) *reinterpret_cast<uint4*>(yb + p * pstride + (long long)(a.L + row) * 64 + pc * 16) = z;
+            }
         }
     }
 }
 
-template <int TQ>
+template <int TQ, int DP>
 static int launch_attn_mfma(const adk_op& op, hipStream_t st)
 {
     AttnMfmaArgs a;
     a.qkv = op.x; a.y = op.y;
     a.B = op.B; a.L = op.L; a.P = op.P; a.Lp = op.L + 2 * op.P; a.M = (long long)op.B * a.Lp;
-    a.heads = op.Cin / ATT_D; a.ntq = (op.L + 32 * TQ - 1) / (32 * TQ);
+    a.heads = op.Cin / (32 * DP); a.ntq = (op.L + 32 * TQ - 1) / (32 * TQ);
     a.nitems = op.B * a.heads * a.ntq;
-    const size_t lds = 4 * 2 * ATT_VBUF;
-    hipLaunchKernelGGL(attn_mfma_kernel<TQ>, dim3((a.nitems + 3) / 4), dim3(256), lds, st, a);
+    const size_t lds = 4 * 2 * DP * ATT_VBUF;
+    hipLaunchKernelGGL((attn_mfma_kernel<TQ, DP>), dim3((a.nitems + 3) / 4), dim3(256), lds, st, a);
+    return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
+}
+
+template <typename T, int D>
+static int launch_attn_valu(const adk_op& op, hipStream_t st)
+{
+    AttnArgs a;
+    a.qkv = op.x; a.y = op.y;
+    a.B = op.B; a.L = op.L; a.P = op.P; a.Lp = op.L + 2 * op.P; a.M = (long long)op.B * a.Lp;
+    a.C = op.Cin; a.heads = op.Cin / D; a.ntq = (op.L + ATT_TQ - 1) / ATT_TQ;
+    dim3 grid(a.ntq, a.heads, op.B);
+    hipLaunchKernelGGL((attn_kernel<T, D>), grid, dim3(64), 0, st, a);
     return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
 }
 
 int launch_attn(const adk_op& op, hipStream_t st)
 {
-    if (op.dtype == ADK_BF16 && op.P * 4 <= 64) return op.L >= 512 ? launch_attn_mfma<2>(op, st) : launch_attn_mfma<1>(op, st);
-    AttnArgs a;
-    a.qkv = op.x; a.y = op.y;
-    a.B = op.B; a.L = op.L; a.P = op.P; a.Lp = op.L + 2 * op.P; a.M = (long long)op.B * a.Lp;
-    a.C = op.Cin; a.heads = op.Cin / ATT_D; a.ntq = (op.L + ATT_TQ - 1) / ATT_TQ;
-    dim3 grid(a.ntq, a.heads, op.B);
-    if (op.dtype == ADK_F32) hipLaunchKernelGGL(attn_kernel<float>, grid, dim3(64), 0, st, a);
-    else hipLaunchKernelGGL(attn_kernel<bf16_t>, grid, dim3(64), 0, st, a);
-    return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
+    const bool d64 = op.i0 == 64;                           // head dim: op.i0 (0 = 32)
+    if (op.dtype == ADK_BF16 && op.P * 4 <= 64) {
+        if (d64) return op.L >= 512 ? launch_attn_mfma<2, 2>(op, st) : launch_attn_mfma<1, 2>(op, st);
+        return op.L >= 512 ? launch_attn_mfma<2, 1>(op, st) : launch_attn_mfma<1, 1>(op, st);
+    }
+    if (op.dtype == ADK_F32) return d64 ? launch_attn_valu<float, 64>(op, st) : launch_attn_valu<float, 32>(op, st);
+    return d64 ? launch_attn_valu<bf16_t, 64>(op, st) : launch_attn_valu<bf16_t, 32>(op, st);
 }

@@ -16,6 +16,8 @@ struct PackArgs {
     const float* noise;                            // optional: N(0,1) draw [B, Cc, L] added to cond scaled by aug[b]
     int B, L, P, Lp, Cx, nplanes, t_stride, Cc, Lc; long long M;
     float cscale;                                  // Lc / L, rounded to f32 like ATen's area_pixel_compute_scale
+    int nemb;                                      // embedding channels: 16, 32 (noise-aug), or 0 (AudioDenoiserModel)
+    const float* xscale;                           // optional f32 [B]: x * c_in[b] (Karras preconditioner, Denoiser.forward)
 };
 
 // Channel order of the network input (decoders/diffusion_decoder.py:146-171):
@@ -28,7 +30,7 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const PackArgs a)
     constexpr int NV = ElemTraits<T>::NV, CB = ElemTraits<T>::CB;
     __shared__ float emb[32];
     const int plane = blockIdx.y, b = blockIdx.z;
-    if (threadIdx.x < 32) {
+    if (threadIdx.x < 32 && a.nemb) {
         const bool second = threadIdx.x >= 16;
         float tv = 0.f;
         if (!second) tv = a.step ? a.t[(long long)(*a.step) * a.t_stride] : a.t[b];
@@ -44,7 +46,8 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const PackArgs a)
     if (r >= a.Lp) return;
     const int l = r - a.P;
     const bool valid = l >= 0 && l < a.L;
-    const int nemb = a.aug ? 32 : 16, c_cond = a.Cx + nemb;
+    const int c_cond = a.Cx + a.nemb;
+    const float xs = a.xscale ? a.xscale[b] : 1.f;
     int i0 = 0, i1 = 0;
     float w0 = 1.f, w1 = 0.f;
     if (a.cond && valid) {
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(256) void pack_input_kernel(const PackArgs a)
             const int c = plane * CB + q * NV + e;
             float v = 0.f;
             if (valid) {
-                if (c < a.Cx) v = a.x[((long long)b * a.Cx + c) * a.L + l];
+                if (c < a.Cx) { v = a.x[((long long)b * a.Cx + c) * a.L + l]; if (a.xscale) v = v * xs; }
                 else if (c < c_cond) v = emb[c - a.Cx];
                 else if (c < c_cond + a.Cc) {
                     const float* cp = a.cond + ((long long)b * a.Cc + (c - c_cond)) * a.Lc;
@@ -93,7 +96,9 @@ int launch_pack_input(const adk_op& op, hipStream_t st)
     a.cscale = a.cond ? (float)a.Lc / (float)op.L : 0.f;
     a.B = op.B; a.L = op.L; a.P = op.P; a.Lp = op.L + 2 * op.P; a.Cx = op.Cin; a.t_stride = op.i0;
     a.M = (long long)op.B * a.Lp;
-    const int Cp = (op.Cin + (a.aug ? 32 : 16) + a.Cc + 31) / 32 * 32;
+    a.nemb = (op.flags & ADK_FLAG_NO_EMBED) ? 0 : (a.aug ? 32 : 16);
+    a.xscale = op.beta;
+    const int Cp = (op.Cin + a.nemb + a.Cc + 31) / 32 * 32;
     const int CB = op.dtype == ADK_F32 ? 16 : 32;
     a.nplanes = Cp / CB;
     dim3 grid((a.Lp + 255) / 256, a.nplanes, op.B);
@@ -102,7 +107,8 @@ int launch_pack_input(const adk_op& op, hipStream_t st)
     return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
 }
 
-struct UnpackArgs { const float* x; float* y; int B, L, P, Lp, C; long long M; };
+struct UnpackArgs { const float* x; float* y; int B, L, P, Lp, C; long long M;
+                    const float* cout; const float* cskip; const float* xin; };   // optional: y = v * c_out[b] + xin * c_skip[b]
 
 __global__ __launch_bounds__(256) void unpack_output_kernel(const UnpackArgs a)
 {
@@ -118,7 +124,15 @@ __global__ __launch_bounds__(256) void unpack_output_kernel(const UnpackArgs a)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int c = plane * 16 + e;
-        if (c < a.C) a.y[((long long)b * a.C + c) * a.L + l] = f[e];
+        if (c < a.C) {
+            const long long o = ((long long)b * a.C + c) * a.L + l;
+            float v = f[e];
+            if (a.cout) {                            // Denoiser.forward (decoders/diffusion_decoder.py:335-337), literal order
+                const float vo = v * a.cout[b], xs = a.xin[o] * a.cskip[b];
+                v = vo + xs;
+            }
+            a.y[o] = v;
+        }
     }
 }
 
@@ -127,6 +141,7 @@ int launch_unpack_output(const adk_op& op, hipStream_t st)
     UnpackArgs a;
     a.x = reinterpret_cast<const float*>(op.x); a.y = reinterpret_cast<float*>(op.y);
     a.B = op.B; a.L = op.L; a.P = op.P; a.Lp = op.L + 2 * op.P; a.C = op.Cin; a.M = (long long)op.B * a.Lp;
+    a.cout = op.gamma; a.cskip = op.beta; a.xin = reinterpret_cast<const float*>(op.residual);
     dim3 grid((op.L + 255) / 256, (op.Cin + 15) / 16, op.B);
     hipLaunchKernelGGL(unpack_output_kernel, grid, dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;

@@ -7,6 +7,11 @@
 // double in a fixed order (bit-reproducible; no atomics), and the pass optionally emits partials of
 // its own output for a following GroupNorm.  16-byte vector loads/stores, per-thread channel slice
 // fixed so gamma/beta live in registers.
+//
+// The same kernel runs GroupNorm(G, C) with G > 1 groups of whole 64-byte channel planes and the ADAPTIVE
+// form AdaGN (reference blocks/blocks.py:53-64: group_norm without affine, then bias + xn * (weight + 1) with
+// per-SAMPLE weight/bias rows produced by a Linear on the noise-level embedding): the statistics must then
+// come from ADK_OP_GN_STATS ([b][plane][row block] partials, so a group is a contiguous range of them).
 #include "adk_common.h"
 
 struct GnArgs {
@@ -16,6 +21,8 @@ struct GnArgs {
     int B, L, P, Lp; long long M;
     int n_in; int RB, nrb, nplanes;
     double count; float eps;
+    int ngroups, C;                              // groups of nplanes / ngroups planes; C = logical channels
+    int mod_stride; float ada;                   // AdaGN: gamma/beta rows per sample (floats), ada = 1 (scale = gamma + 1)
 };
 
 template <typename T, bool GELU, bool APPLY>
@@ -29,12 +36,16 @@ __global__ __launch_bounds__(256) void gn_kernel(const GnArgs a)
     float scale[NV], shift[NV];
     if (APPLY) {
         float mean, rstd;
-        gn_finalize(a.partials_in + (long long)b * a.n_in * 2, a.n_in, a.count, a.eps, mean, rstd, red);
+        const int n_g = a.n_in / a.ngroups, g = plane / (a.nplanes / a.ngroups);
+        gn_finalize(a.partials_in + ((long long)b * a.n_in + (long long)g * n_g) * 2, n_g, a.count, a.eps, mean, rstd, red);
         const int c0 = plane * CB + q * NV;
+        const float* gm = a.gamma + (long long)b * a.mod_stride;
+        const float* bt = a.beta + (long long)b * a.mod_stride;
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
-            scale[e] = a.gamma[c0 + e] * rstd;
-            shift[e] = a.beta[c0 + e] - mean * scale[e];
+            const bool real = c0 + e < a.C;          // pad channels stay exactly zero
+            scale[e] = real ? (gm[c0 + e] + a.ada) * rstd : 0.f;
+            shift[e] = real ? bt[c0 + e] - mean * scale[e] : 0.f;
         }
     }
     const long long rowbase = (long long)plane * a.M + (long long)b * a.Lp;
@@ -121,7 +132,11 @@ static int launch_gn_t(const adk_op& op, hipStream_t st, bool apply)
     a.B = op.B; a.L = op.L; a.P = op.P; a.Lp = op.L + 2 * op.P; a.M = (long long)op.B * a.Lp;
     a.n_in = op.n_partials_in;
     a.RB = gn_rb(op.L); a.nrb = (op.L + a.RB - 1) / a.RB; a.nplanes = (op.Cin + CB - 1) / CB;
-    a.count = (double)op.Cin * (double)op.L; a.eps = op.f0;
+    a.ngroups = op.i1 > 1 ? op.i1 : 1;
+    a.C = op.Cin;
+    a.count = (double)(op.Cin / a.ngroups) * (double)op.L; a.eps = op.f0;
+    a.mod_stride = (op.flags & ADK_FLAG_ADA) ? op.i0 : 0;
+    a.ada = (op.flags & ADK_FLAG_ADA) ? 1.f : 0.f;
     dim3 grid(a.nrb, a.nplanes, op.B);
     if (!apply) hipLaunchKernelGGL((gn_kernel<T, false, false>), grid, dim3(256), 0, st, a);
     else if (op.flags & ADK_FLAG_GELU) hipLaunchKernelGGL((gn_kernel<T, true, true>), grid, dim3(256), 0, st, a);

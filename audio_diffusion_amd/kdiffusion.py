@@ -1,0 +1,371 @@
+"""AudioDenoiserModel + Denoiser: drop-ins for the reference k-diffusion ("audio_v1") denoiser family
+(decoders/diffusion_decoder.py:261-337; blocks/blocks.py:53-64, 89-144, 260-316), executed like
+DiffusionAttnUnet1D as a flat plan of libadk kernel launches.
+
+* Same constructor signatures, ``state_dict`` keys/shapes and construction-time RNG consumption as the reference.
+* ``model(input, sigma, mapping_cond=None, unet_cond=None, log_sigma=True)`` and ``Denoiser(model)(x, sigma)``.
+* Lowering: the noise-level embedding, MappingNet and EVERY AdaGN mapper of the network run up front as four tiny
+  fp32 launches (the mappers only depend on the embedding, so their weights are stacked into one matrix and one
+  launch yields each layer's per-sample (weight, bias) rows); each ResModConvBlock is then
+  gn_stats -> AdaGN+GELU -> 3-tap MFMA conv -> gn_stats -> AdaGN+GELU -> 3-tap conv (+ skip in the epilogue);
+  the U-Net's ``torch.cat([x, skip])`` is concat-free (both halves are written in place by their producers);
+  the learned resamplers reuse the phase fold of unet.py.  Dropout is inference-mode (identity).
+* No CPU or eager fallback.
+"""
+import ctypes
+
+import torch
+from torch import nn
+
+from . import _lib
+from .blocks import (AdaGN, DBlock, FourierFeatures, MappingNet, ResModConvBlock, SelfAttentionMod1d, UBlock, UNet)
+from .unet import _Plan, _ceil_to
+
+
+class _KPlan(_Plan):
+    """Compiled AudioDenoiserModel.forward for one (B, L, dtype, cond_len, flags)."""
+
+    def __init__(self, model, B, L, dtype, device, cond_len=0, log_sigma=True, has_mapping_cond=False, scaled=False):
+        self.log_sigma, self.has_mapping_cond, self.scaled = log_sigma, has_mapping_cond, scaled
+        super().__init__(model, B, L, dtype, device, None, cond_len)
+
+    # ---- conditioning front end ----------------------------------------------------------------------
+    def _f32(self, key, t):
+        return self._dev(("f32", key), lambda: t.detach().to(self.device, torch.float32).contiguous())
+
+    def _linear(self, x_off, x_stride, cin, key, weight, bias, y_off, y_stride, gelu=False, res_off=None, res_stride=0):
+        ptrs = {"x": x_off, "y": ("arena", y_off), "w": ("abs", self._f32(key + ".weight", weight))}
+        if bias is not None:
+            ptrs["bias"] = ("abs", self._f32(key + ".bias", bias))
+        if res_off is not None:
+            ptrs["residual"] = ("arena", res_off)
+        self._emit(_lib.OP_LINEAR, ptrs, flags=_lib.FLAG_GELU if gelu else 0, Cin=cin, Cout=weight.shape[0],
+                   i0=x_stride, i1=res_stride, i2=y_stride)
+
+    def _conditioning(self):
+        """c_noise embedding -> MappingNet -> the stacked AdaGN mappers (decoders/diffusion_decoder.py:297-305)."""
+        m, B = self.model, self.B
+        F = m.feats_in
+        emb = self.raw(B * F * 4)
+        self._emit(_lib.OP_FOURIER, {"x": ("t", 0), "w": ("abs", self._f32("timestep_embed.weight", m.timestep_embed.weight)),
+                                     "y": ("arena", emb.off)}, flags=_lib.FLAG_LOG if self.log_sigma else 0, Cout=F, i2=F)
+        if self.has_mapping_cond:                       # timestep_embed + mapping_cond(mapping_cond)   (:301,304)
+            e2 = self.raw(B * F * 4)
+            self._linear(("mapcond", 0), m.mapping_cond_dim, m.mapping_cond_dim, "mapping_cond", m.mapping_cond.weight, None,
+                         e2.off, F, res_off=emb.off, res_stride=F)
+            self.free(emb)
+            emb = e2
+        h = self.raw(B * F * 4)
+        self._linear(("arena", emb.off), F, F, "mapping.0", m.mapping[0].weight, m.mapping[0].bias, h.off, F, gelu=True)
+        cond = self.raw(B * F * 4)
+        self._linear(("arena", h.off), F, F, "mapping.2", m.mapping[2].weight, m.mapping[2].bias, cond.off, F, gelu=True)
+        self.free(emb, h)
+
+        # every AdaGN mapper (blocks/blocks.py:59,62) in one matrix; a layer's rows = [weight | pad | bias | pad]
+        self.ada_off, rows, total = {}, [], 0
+        for name, mod in m.named_modules():
+            if isinstance(mod, AdaGN):
+                cp = _ceil_to(mod.c_out, 32)
+                self.ada_off[id(mod)] = (total, total + cp)
+                rows.append((name, mod, cp))
+                total += 2 * cp
+        self.ada_stride = total
+
+        def stack():
+            W = torch.zeros(total, F)
+            bvec = torch.zeros(total)
+            o = 0
+            for _, mod, cp in rows:
+                w, bb, c = mod.mapper.weight.detach().float().cpu(), mod.mapper.bias.detach().float().cpu(), mod.c_out
+                W[o:o + c], W[o + cp:o + cp + c] = w[:c], w[c:]
+                bvec[o:o + c], bvec[o + cp:o + cp + c] = bb[:c], bb[c:]
+                o += 2 * cp
+            return torch.cat([W.reshape(-1), bvec]).to(self.device)
+        packed = self._dev(("adagn_stack",), stack)
+        self.ada_table = self.raw(B * total * 4)
+        self._emit(_lib.OP_LINEAR, {"x": ("arena", cond.off), "y": ("arena", self.ada_table.off), "w": ("abs", packed),
+                                    "bias": ("abs", packed + total * F * 4)}, Cin=F, Cout=total, i0=F, i2=total)
+        self.free(cond)
+
+    # ---- blocks --------------------------------------------------------------------------------------
+    def adagn(self, x, mod, gelu, out=None):
+        """AdaGN [+ GELU] (blocks/blocks.py:61-64).  Statistics: one gn_stats pass over x."""
+        g = mod.num_groups
+        cb = 16 if x.f32 else 32
+        if g > 1 and (x.C % g or (x.C // g) % cb):
+            raise NotImplementedError(f"AdaGN with {g} groups over {x.C} channels: groups must be whole {cb}-channel planes")
+        sop = self._emit(_lib.OP_GN_STATS, {"x": ("arena", x.off)}, L=x.L, Cin=x.C)
+        n = self.lib.adk_partials_count(ctypes.byref(sop))
+        part = self.raw(self.B * n * 8)
+        self._ops[-1][1]["partials_out"] = ("arena", part.off)
+        esz = 4 if x.f32 else 2
+        self.meta[-1].update(L=x.L, c=x.C, bytes=float(self.B) * x.C * x.L * esz)
+        y = out if out is not None else x
+        w_off, b_off = self.ada_off[id(mod)]
+        self._emit(_lib.OP_GN_APPLY, {"x": ("arena", x.off), "y": ("arena", y.off), "partials_in": ("arena", part.off),
+                                      "gamma": ("arena", self.ada_table.off + 4 * w_off),
+                                      "beta": ("arena", self.ada_table.off + 4 * b_off)},
+                   flags=_lib.FLAG_ADA | (_lib.FLAG_GELU if gelu else 0), L=x.L, Cin=x.C, Cout=x.C, n_partials_in=n,
+                   f0=mod.eps, i0=self.ada_stride, i1=g)
+        self.meta[-1].update(L=x.L, c=x.C, bytes=2.0 * self.B * x.C * x.L * esz)
+        self.free(part)
+        return y
+
+    def res_mod_block(self, blk, key, x, out=None):
+        """ResModConvBlock (blocks/blocks.py:89-101, 48-50).  Does not free x."""
+        a1, c1, a2, c2 = blk.main[0], blk.main[2], blk.main[4], blk.main[6]
+        h = self.adagn(x, a1, True, out=self.tensor(x.C, x.L))
+        raw1, _ = self.conv(h, key + "main.2", c1.weight, c1.bias, blk.c_mid)
+        self.free(h)
+        self.adagn(raw1, a2, True)
+        r = x
+        if isinstance(blk.skip, nn.Conv1d):
+            r, _ = self.conv(x, key + "skip", blk.skip.weight, None, blk.c_out)
+        y, _ = self.conv(raw1, key + "main.6", c2.weight, c2.bias, blk.c_out, residual=r, out=out)
+        self.free(raw1)
+        if r is not x:
+            self.free(r)
+        return y
+
+    def attention_mod(self, att, key, x, out=None):
+        """SelfAttentionMod1d (blocks/blocks.py:134-144).  Frees x."""
+        n = self.adagn(x, att.norm_in, False, out=self.tensor(x.C, x.L))
+        qkv, _ = self.conv(n, key + "qkv_proj", att.qkv_proj.weight, att.qkv_proj.bias, 3 * x.C)
+        self.free(n)
+        y = self.tensor(x.C, x.L)
+        self._emit(_lib.OP_ATTN, {"x": ("arena", qkv.off), "y": ("arena", y.off)}, L=x.L, Cin=x.C, i0=x.C // att.n_head)
+        self.meta[-1].update(L=x.L, c=x.C, attn_flops=4.0 * x.L * x.L * x.C * self.B)
+        self.free(qkv)
+        o, _ = self.conv(y, key + "out_proj", att.out_proj.weight, att.out_proj.bias, x.C, residual=x, out=out)
+        self.free(y, x)
+        return o
+
+    def layers(self, mods, keys, x, final_out=None, keep_input=False):
+        """A run of ResModConvBlock / SelfAttentionMod1d modules; frees intermediates (and x unless keep_input)."""
+        cur, owned = x, not keep_input
+        for j, (mod, key) in enumerate(zip(mods, keys)):
+            out = final_out if j == len(mods) - 1 else None
+            if isinstance(mod, ResModConvBlock):
+                y = self.res_mod_block(mod, key, cur, out=out)
+                if owned:
+                    self.free(cur)
+            else:
+                y = self.attention_mod(mod, key, cur, out=out)         # frees cur itself
+            cur, owned = y, True
+        return cur
+
+    def _build(self):
+        m, B = self.model, self.B
+        L0 = self.T
+        self._conditioning()
+        has_cond = self.cond_len > 0
+        cin0 = m.c_in + (m.unet_cond_dim if has_cond else 0)
+        x0 = self.tensor(_ceil_to(cin0, 32), L0)
+        x0.C = cin0
+        ptrs = {"x": ("input", 0), "y": ("arena", x0.off)}
+        extra = {}
+        if has_cond:
+            ptrs["residual"] = ("cond", 0)
+            extra = dict(Cout=m.unet_cond_dim, i1=self.cond_len)
+        if self.scaled:
+            ptrs["beta"] = ("cin", 0)
+        self._emit(_lib.OP_PACK_INPUT, ptrs, flags=_lib.FLAG_NO_EMBED, L=L0, Cin=m.c_in, **extra)
+
+        n = len(m.depths)
+        ch = m.channels
+        d_blocks, u_blocks = m.u_net.d_blocks, m.u_net.u_blocks          # u_blocks: deepest first
+        # level j's concat buffer: half 0 <- UBlock(j+1) output, half 1 <- DBlock(j) output (blocks/blocks.py:288-289)
+        cats = [None] * n
+        cur = None
+        for j in range(n):
+            blk = d_blocks[j]
+            mods = list(blk)
+            keys = [f"u_net.d_blocks.{j}.{k}." for k in range(len(mods))]
+            if j == 0:
+                h, _ = self.conv(x0, "proj_in", m.proj_in.weight, m.proj_in.bias, ch[0])
+                self.free(x0)
+                owned = True
+            else:
+                h, owned = cur, False                                     # the skip of level j-1: stays alive
+                if blk.ratio > 1:
+                    h = self.resample_down(mods[0], keys[0], h)
+                    mods, keys, owned = mods[1:], keys[1:], True
+            if j < n - 1:
+                cats[j] = self.tensor(2 * ch[j], h.L)
+                dst = self.half(cats[j], 1, ch[j])
+            else:
+                dst = None
+            cur = self.layers(mods, keys, h, final_out=dst, keep_input=not owned)
+        # up path
+        x = cur
+        for i in range(n):
+            j = n - 1 - i
+            blk = u_blocks[i]
+            mods = list(blk)
+            keys = [f"u_net.u_blocks.{i}.{k}." for k in range(len(mods))]
+            up = mods[-1] if blk.ratio > 1 else None
+            if up is not None:
+                mods, keys_l = mods[:-1], keys[:-1]
+            else:
+                keys_l = keys
+            src = x if i == 0 else cats[j]
+            dst = self.half(cats[j - 1], 0, ch[j - 1]) if j > 0 else None
+            if up is None:
+                y = self.layers(mods, keys_l, src, final_out=dst)
+            else:
+                u = self.layers(mods, keys_l, src)
+                self.resample_up(up, keys[-1], u, dst)
+                self.free(u)
+                y = dst
+            x = y
+        o, _ = self.conv(x, "proj_out", m.proj_out.weight, m.proj_out.bias, m.c_in, out_f32=True)
+        self.free(x)
+        ptrs = {"x": ("arena", o.off), "y": ("output", 0)}
+        if self.scaled:                                                   # Denoiser.forward (:335-337)
+            ptrs.update(gamma=("cout", 0), beta=("cskip", 0), residual=("input", 0))
+        self._emit(_lib.OP_UNPACK_OUTPUT, ptrs, L=L0, Cin=m.c_in)
+
+
+class AudioDenoiserModel(nn.Module):
+    """Drop-in for the reference class of the same name (decoders/diffusion_decoder.py:261-312)."""
+
+    kernel_size = 3                       # halo rows of the activation layout: every conv here has <= 3 taps
+
+    def __init__(self, c_in, feats_in, depths, channels, self_attn_depths, strides, mapping_cond_dim=0, unet_cond_dim=0,
+                 dropout_rate=0.):
+        super().__init__()
+        self.c_in, self.feats_in = c_in, feats_in
+        self.depths, self.channels, self.strides = list(depths), list(channels), list(strides)
+        self.mapping_cond_dim, self.unet_cond_dim = mapping_cond_dim, unet_cond_dim
+        # construction order == reference (:275-294)
+        self.timestep_embed = FourierFeatures(1, feats_in)
+        if mapping_cond_dim > 0:
+            self.mapping_cond = nn.Linear(mapping_cond_dim, feats_in, bias=False)
+        self.mapping = MappingNet(feats_in, feats_in)
+        self.proj_in = nn.Conv1d(c_in + unet_cond_dim, channels[0], 1)
+        self.proj_out = nn.Conv1d(channels[0], c_in, 1)
+        nn.init.zeros_(self.proj_out.weight)
+        nn.init.zeros_(self.proj_out.bias)
+        d_blocks, u_blocks = [], []
+        n = len(depths)
+        for i in range(n):
+            ci = channels[i] if i == 0 else channels[i - 1]
+            st = 1 if i == 0 else strides[i - 1]
+            d_blocks.append(DBlock(depths[i], feats_in, ci, channels[i], channels[i], downsample_ratio=st,
+                                   self_attn=self_attn_depths[i], dropout_rate=dropout_rate))
+        for i in range(n):
+            ci = channels[i] * 2 if i < n - 1 else channels[i]
+            co = channels[i] if i == 0 else channels[i - 1]
+            st = 1 if i == 0 else strides[i - 1]
+            u_blocks.append(UBlock(depths[i], feats_in, ci, channels[i], co, upsample_ratio=st,
+                                   self_attn=self_attn_depths[i], dropout_rate=dropout_rate))
+        self.u_net = UNet(d_blocks, list(reversed(u_blocks)))
+        self.compute_dtype = None          # None: fp32 (bf16 under torch.autocast)
+        self._wcache = {}
+        self._plans = {}
+
+    # ---- cache management (same contract as DiffusionAttnUnet1D) ----
+    def invalidate_cache(self):
+        self._wcache = {}
+        self._plans = {}
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self.invalidate_cache()
+        return out
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self.invalidate_cache()
+        return out
+
+    def check_input(self, x):
+        if x.dim() != 3 or x.shape[1] != self.c_in:
+            raise RuntimeError(f"expected input of shape [B, {self.c_in}, L], got {tuple(x.shape)} "
+                               "(the reference fails in proj_in with a channel mismatch)")
+        lin = x.shape[2]
+        for i in range(1, len(self.depths)):
+            f = self.strides[i - 1]
+            if lin % f or lin // f < 1:
+                raise RuntimeError(f"level {i}: length {lin} is not a multiple of its stride {f} "
+                                   "(the reference fails in torch.cat with mismatched lengths)")
+            lin //= f
+
+    def resolve_dtype(self):
+        if self.compute_dtype is not None:
+            return self.compute_dtype
+        return torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+
+    def plan_for(self, B, L, dtype, device, cond_len=0, log_sigma=True, has_mapping_cond=False, scaled=False):
+        key = (B, L, dtype, str(device), cond_len, log_sigma, has_mapping_cond, scaled)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = _KPlan(self, B, L, dtype, device, cond_len, log_sigma, has_mapping_cond, scaled)
+            self._plans[key] = plan
+        return plan
+
+    @torch.no_grad()
+    def run(self, input, sigma, mapping_cond=None, unet_cond=None, log_sigma=True, scalings=None):
+        """forward() plus the optional Karras scalings (c_skip, c_out, c_in) of Denoiser.forward, fused into the
+        boundary kernels."""
+        if not input.is_cuda:
+            raise RuntimeError("AudioDenoiserModel (MI355X build) runs on ROCm devices only; there is no CPU path")
+        self.check_input(input)
+        dev, B = input.device, input.shape[0]
+        x = input.detach().to(torch.float32).contiguous()
+        sig = sigma.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        if sig.numel() != B:
+            raise ValueError(f"sigma must have one entry per batch item, got {tuple(sigma.shape)}")
+        if mapping_cond is not None and self.mapping_cond_dim == 0:
+            raise AttributeError("'AudioDenoiserModel' object has no attribute 'mapping_cond'")     # the reference's error
+        mc = None
+        if mapping_cond is not None:
+            mc = mapping_cond.detach().to(device=dev, dtype=torch.float32).contiguous()
+            if mc.shape != (B, self.mapping_cond_dim):
+                raise RuntimeError(f"expected mapping_cond of shape [{B}, {self.mapping_cond_dim}], got {tuple(mc.shape)}")
+        uc = None
+        if unet_cond is not None:
+            uc = unet_cond.detach().to(device=dev, dtype=torch.float32).contiguous()
+            if uc.dim() != 3 or uc.shape[0] != B or uc.shape[1] != self.unet_cond_dim or self.unet_cond_dim == 0:
+                raise RuntimeError(f"expected unet_cond of shape [{B}, {self.unet_cond_dim}, Lc], got {tuple(uc.shape)} "
+                                   "(the reference fails in proj_in with a channel mismatch)")
+        elif self.unet_cond_dim:
+            raise RuntimeError(f"this model was built with unet_cond_dim={self.unet_cond_dim}: forward() needs `unet_cond`")
+        plan = self.plan_for(B, x.shape[2], self.resolve_dtype(), dev, cond_len=uc.shape[2] if uc is not None else 0,
+                             log_sigma=bool(log_sigma), has_mapping_cond=mc is not None, scaled=scalings is not None)
+        out = torch.empty_like(x)
+        ptrs = dict(input=x.data_ptr(), t=sig.data_ptr(), output=out.data_ptr(), cond=uc.data_ptr() if uc is not None else 0,
+                    mapcond=mc.data_ptr() if mc is not None else 0)
+        keep = []
+        if scalings is not None:
+            keep = [s.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous() for s in scalings]
+            ptrs.update(cskip=keep[0].data_ptr(), cout=keep[1].data_ptr(), cin=keep[2].data_ptr())
+        plan.bind_named(**ptrs)
+        plan.run(torch.cuda.current_stream(dev).cuda_stream)
+        return out
+
+    def forward(self, input, sigma, mapping_cond=None, unet_cond=None, log_sigma=True):
+        return self.run(input, sigma, mapping_cond, unet_cond, log_sigma)
+
+
+class Denoiser(nn.Module):
+    """Karras et al. preconditioner, drop-in for decoders/diffusion_decoder.py:314-337 (inference part:
+    ``get_scalings`` and ``forward``; ``loss`` is training-only and not provided)."""
+
+    def __init__(self, inner_model, sigma_data=1.):
+        super().__init__()
+        self.inner_model = inner_model
+        self.sigma_data = sigma_data
+
+    def get_scalings(self, sigma):
+        c_skip = self.sigma_data ** 2 / (sigma ** 2 + self.sigma_data ** 2)
+        c_out = sigma * self.sigma_data / (sigma ** 2 + self.sigma_data ** 2) ** 0.5
+        c_in = 1 / (sigma ** 2 + self.sigma_data ** 2) ** 0.5
+        return c_skip, c_out, c_in
+
+    def loss(self, *a, **k):
+        raise NotImplementedError("Denoiser.loss is training-only; this build covers the sampling path")
+
+    def forward(self, x, sigma, **kwargs):
+        # inner(x * c_in, sigma) * c_out + x * c_skip, with both scalings fused into the pack / unpack kernels
+        return self.inner_model.run(x, sigma, scalings=self.get_scalings(sigma), **kwargs)

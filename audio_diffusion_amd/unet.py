@@ -403,7 +403,7 @@ class _Plan:
                 elif kind == "abs":
                     setattr(op, field, val)
                 else:
-                    self._patch[kind].append((i, field))
+                    self._patch.setdefault(kind, []).append((i, field))
             self.ops[i] = op
         self.n_ops = n
         del self._ops
@@ -413,6 +413,12 @@ class _Plan:
                           ("noise", noise_ptr)):
             for i, f in self._patch[kind]:
                 setattr(self.ops[i], f, ptr)
+
+    def bind_named(self, **ptrs):
+        """Patch caller-owned pointers by kind name (``input=..., output=..., ...``); 0 leaves a field NULL."""
+        for kind, ptr in ptrs.items():
+            for i, f in self._patch.get(kind, ()):
+                setattr(self.ops[i], f, ptr or None)
 
     def run(self, stream_ptr):
         _lib.run_ops(self.ops, self.n_ops, stream_ptr)

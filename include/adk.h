@@ -52,13 +52,20 @@ enum {
     ADK_OP_STEP_ADVANCE = 12, /* device-side step counter ++ (lets one hipGraph replay every step)   */
     ADK_OP_AUDIO_TO_INT16 = 13, /* demo output stage: train_uncond.py:182-187                         */
     ADK_OP_SPACE_TO_DEPTH = 14, /* phase fold in front of Downsample1d_2's strided conv: blocks/blocks.py:214-226 */
-    ADK_OP_DEPTH_TO_SPACE = 15  /* phase unfold behind Upsample1d_2's transposed conv:   blocks/blocks.py:229-255 */
+    ADK_OP_DEPTH_TO_SPACE = 15, /* phase unfold behind Upsample1d_2's transposed conv:   blocks/blocks.py:229-255 */
+    ADK_OP_LINEAR = 16,       /* nn.Linear on [B, F] rows: MappingNet, mapping_cond, the AdaGN mappers
+                                 (blocks/blocks.py:59,62,292-301; decoders/diffusion_decoder.py:277-278,301-304) */
+    ADK_OP_FOURIER = 17       /* FourierFeatures(1, F) of c_noise = log(sigma)/4: decoders/diffusion_decoder.py:297-300 */
 };
 
 /* flags */
 #define ADK_FLAG_GELU 1u        /* GN_APPLY: apply exact (erf) GELU after the affine            */
 #define ADK_FLAG_OUT_F32 2u     /* CONV: output (and residual) tensors are f32 CPL even if dtype=bf16 */
 #define ADK_FLAG_NOISE 4u       /* DDIM_UPDATE: add c * noise (eta > 0)                           */
+#define ADK_FLAG_ADA 8u         /* GN_APPLY: AdaGN (blocks/blocks.py:61-64): gamma/beta are per-SAMPLE rows
+                                   (row stride i0 floats) and the scale is gamma + 1                */
+#define ADK_FLAG_LOG 16u        /* FOURIER: embed log(sigma)/4 instead of sigma                    */
+#define ADK_FLAG_NO_EMBED 32u   /* PACK_INPUT: no timestep-embedding channels ([x | cond] only)    */
 
 /* One flat descriptor for every op kind; unused fields are 0/NULL.  Field use per kind is
  * documented at the matching adk_* entry point below (same names). */
@@ -132,6 +139,39 @@ int adk_fir_up2(int dtype, int B, int L, int P, int C, int K, const float *taps,
 /* Replaces the attention core of SelfAttention1d.forward (blocks/blocks.py:116-121):
  *   qkv CPL [B,3C,L] (channel order q-heads,k-heads,v-heads; head dim 32) -> y CPL [B,C,L]. */
 int adk_attn1d(int dtype, int B, int L, int P, int C, const void *qkv, void *y, void *stream);
+
+/* The same for SelfAttentionMod1d (blocks/blocks.py:134-144; DBlock/UBlock head_size 64): head_dim 32 or 64. */
+int adk_attn1d_hd(int dtype, int B, int L, int P, int C, int head_dim, const void *qkv, void *y, void *stream);
+
+/* Replaces AdaGN.forward (blocks/blocks.py:61-64) [+ nn.GELU, flag ADK_FLAG_GELU]: F.group_norm(x, groups) then
+ * bias[b] + xn * (weight[b] + 1).  weight/bias f32, one row of `row_stride` floats per sample (the two halves of the
+ * mapper's output, :62).  Groups must be whole channel planes (C/groups a multiple of 16 f32 / 32 bf16) or 1;
+ * partials_in = adk_gn_stats of x ([B][adk_partials_count][2]).  y may alias x. */
+int adk_adagn_apply(int dtype, uint32_t flags, int B, int L, int P, int C, int groups, float eps,
+                    const void *x, const float *partials_in, int n_partials_in,
+                    const float *weight, const float *bias, int row_stride, void *y, void *stream);
+
+/* Replaces nn.Linear on per-sample rows (MappingNet blocks/blocks.py:292-301, mapping_cond and the AdaGN mappers
+ * blocks/blocks.py:59,62): y[b][o] = act(sum_i w[o][i] x[b][i] + bias[o] + residual[b][o]), all f32, w row-major
+ * [Cout][Cin]; bias/residual may be NULL; act = exact GELU with ADK_FLAG_GELU; strides in floats. */
+int adk_linear(uint32_t flags, int B, int Cin, int Cout, const float *x, int x_stride, const float *w, const float *bias,
+               const float *residual, int res_stride, float *y, int y_stride, void *stream);
+
+/* Replaces timestep_embed(append_dims(c_noise, 2)) of AudioDenoiserModel.forward (decoders/diffusion_decoder.py:297-300):
+ * y[b] = [cos(2 pi s w) | sin(2 pi s w)], s = log(sigma[b]) / 4 with ADK_FLAG_LOG else sigma[b]; w f32 [F/2]. */
+int adk_fourier_features(uint32_t flags, int B, int F, const float *sigma, const float *w, float *y, int y_stride,
+                         void *stream);
+
+/* Input boundary of AudioDenoiserModel.forward (decoders/diffusion_decoder.py:306-308) with the Karras input scaling of
+ * Denoiser.forward (:336-337): y CPL [B, roundup(Cx + Cc, 32), L] = [x * x_scale[b] | interpolate(cond)], x_scale and
+ * cond optional (NULL). */
+int adk_pack_input_plain(int dtype, int B, int L, int P, int Cx, const float *x, const float *x_scale,
+                         const float *cond, int Cc, int Lc, void *y, void *stream);
+
+/* Output boundary with the Karras skip of Denoiser.forward (decoders/diffusion_decoder.py:337):
+ * y = unpack(x) * c_out[b] + x_in * c_skip[b]   (x_in = the UNSCALED network input, f32 NCL). */
+int adk_unpack_output_scaled(int B, int L, int P, int C, const float *x, const float *c_out, const float *c_skip,
+                             const float *x_in, float *y, void *stream);
 
 /* Replaces FourierFeatures + expand_to_planes + torch.cat (blocks/blocks.py:161-167,
  * decoders/diffusion_decoder.py:144-171):  x f32 [B,Cx,L] (NCL), t: f32 [B] if t_table==0, else

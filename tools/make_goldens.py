@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate golden vectors by IMPORTING the reference (this container only).
 
-Run:  python tools/make_goldens.py [--tier B T C R F] [--ref /root/reference]
+Run:  python tools/make_goldens.py [--tier B T C R K F] [--ref /root/reference]
 Writes small fixtures (inputs + expected outputs, never source text) to tests/golden/.
 
 The reference's hot path is Python; three of its imports are unavailable or have drifted in this
@@ -258,6 +258,44 @@ def tier_cond(Model, sampling):
                     (2, 2, 1024), 100, seed=42, aug_scale=0.0)
 
 
+def tier_kdiff():
+    """AudioDenoiserModel + Denoiser (decoders/diffusion_decoder.py:261-337), SURVEY 8 f4.  proj_out is zero-initialised
+    by the reference (:281-282), so its parameters are re-drawn to make the fixtures informative."""
+    print("tier K: k-diffusion denoiser family (SURVEY 8 f4)")
+    from decoders.diffusion_decoder import AudioDenoiserModel, Denoiser
+    cases = {
+        # c_in, feats_in, depths, channels, self_attn_depths, strides, extra ctor kwargs, L, cond_len, sigma_data
+        "kdiff_tiny": (dict(c_in=2, feats_in=32, depths=[1, 2, 2], channels=[32, 64, 64],
+                            self_attn_depths=[False, False, True], strides=[4, 2]), 256, 0, 0.5),
+        "kdiff_attn128": (dict(c_in=4, feats_in=64, depths=[2, 1, 1], channels=[64, 128, 128],
+                               self_attn_depths=[False, True, True], strides=[2, 3]), 384, 0, 1.0),
+        "kdiff_cond": (dict(c_in=2, feats_in=32, depths=[1, 1], channels=[32, 32], self_attn_depths=[False, True],
+                            strides=[2], mapping_cond_dim=5, unet_cond_dim=3), 128, 19, 0.25),
+    }
+    for i, (name, (kw, L, cond_len, sigma_data)) in enumerate(cases.items()):
+        torch.manual_seed(60 + i)
+        m = AudioDenoiserModel(**kw).eval()
+        torch.manual_seed(160 + i)
+        with torch.no_grad():
+            m.proj_out.weight.normal_(0, 0.2)
+            m.proj_out.bias.normal_(0, 0.1)
+        x = torch.randn(2, kw["c_in"], L)
+        sigma = torch.tensor([0.05, 2.0])
+        extra = {}
+        if cond_len:
+            extra = dict(mapping_cond=torch.randn(2, kw["mapping_cond_dim"]), unet_cond=torch.randn(2, kw["unet_cond_dim"], cond_len))
+        with torch.no_grad():
+            y = m(x, sigma, **extra)
+            y_nolog = m(x, sigma, log_sigma=False, **extra)
+            # Denoiser.forward (:336) builds its scalings with `append_dims(x, x.ndim) for x in ...`: the comprehension
+            # variable shadows the input, nothing is appended, and the broadcast only works for batch size 1 -- so the
+            # reference is called one sample at a time (per-sample scaling is what it computes there)
+            dn = Denoiser(m, sigma_data=sigma_data)
+            d = torch.cat([dn(x[b:b + 1], sigma[b:b + 1], **{k: v[b:b + 1] for k, v in extra.items()}) for b in range(2)])
+        npz(name + ".npz", seed=np.int64(60 + i), x=x, sigma=sigma, y=y, y_nolog=y_nolog, denoised=d, sigma_data=np.float32(sigma_data),
+            cfg=np.bytes_(json.dumps(kw).encode()), **{"extra/" + k: v for k, v in extra.items()}, **sd_arrays(m.state_dict()))
+
+
 def tier_full(Model, sampling):
     print("tier F: full 221M-param uncond model (seeds 0/1), digests + 10-step output")
     torch.manual_seed(0)
@@ -301,7 +339,7 @@ def tier_full(Model, sampling):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--tier", nargs="+", default=["B", "T", "C", "R", "F"])
+    ap.add_argument("--tier", nargs="+", default=["B", "T", "C", "R", "K", "F"])
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     P, Model, sampling, blocks = import_reference(a.ref)
@@ -313,6 +351,8 @@ def main():
         tier_cond(Model, sampling)
     if "R" in a.tier:
         tier_learned(Model, sampling)
+    if "K" in a.tier:
+        tier_kdiff()
     if "F" in a.tier:
         tier_full(Model, sampling)
 

@@ -17,7 +17,7 @@ OP_PACK_INPUT, OP_UNPACK_OUTPUT, OP_PQMF_ANALYSIS, OP_PQMF_SYNTHESIS = 7, 8, 9, 
 OP_DDIM_UPDATE, OP_STEP_ADVANCE, OP_AUDIO_TO_INT16, OP_SPACE_TO_DEPTH, OP_DEPTH_TO_SPACE = 11, 12, 13, 14, 15
 OP_LINEAR, OP_FOURIER = 16, 17
 
-FLAG_GELU, FLAG_OUT_F32, FLAG_NOISE, FLAG_ADA, FLAG_LOG, FLAG_NO_EMBED = 1, 2, 4, 8, 16, 32
+FLAG_GELU, FLAG_OUT_F32, FLAG_NOISE, FLAG_ADA, FLAG_LOG, FLAG_NO_EMBED, FLAG_GROUP_STATS, FLAG_WT = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 class AdkOp(C.Structure):

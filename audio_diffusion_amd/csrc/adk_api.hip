@@ -63,6 +63,8 @@ static int validate(const adk_op& o)
         REQUIRE(o.CoutPad >= o.Cout && o.CoutPad % bn == 0, "conv1d: CoutPad=%d must be a multiple of %d >= Cout=%d",
                 o.CoutPad, bn, o.Cout);
         REQUIRE(o.x && o.w && o.y, "conv1d: null tensor");
+        REQUIRE(!(o.flags & ADK_FLAG_GROUP_STATS) || !(o.flags & ADK_FLAG_OUT_F32) || o.dtype == ADK_F32,
+                "conv1d: group statistics of an f32 output need dtype f32");
         return ADK_OK;
     }
     case ADK_OP_GN_APPLY:
@@ -74,9 +76,8 @@ static int validate(const adk_op& o)
             const int cb = cb_of(o.dtype);
             REQUIRE(o.Cin % o.i1 == 0 && (o.Cin / o.i1) % cb == 0,
                     "gn_apply: %d groups of C=%d are not whole %d-channel planes", o.i1, o.Cin, cb);
-            REQUIRE(o.n_partials_in == gn_partials_count(o.dtype, o.Cin, o.L),
-                    "gn_apply: grouped statistics must come from gn_stats (%d partials per sample, got %d)",
-                    gn_partials_count(o.dtype, o.Cin, o.L), o.n_partials_in);
+            REQUIRE(o.n_partials_in % o.i1 == 0, "gn_apply: %d partials per sample do not split into %d groups "
+                    "(grouped statistics come from gn_stats or a conv with ADK_FLAG_GROUP_STATS)", o.n_partials_in, o.i1);
         }
         if (o.flags & ADK_FLAG_ADA) REQUIRE(o.i0 >= o.Cin, "gn_apply: AdaGN row stride %d < C=%d", o.i0, o.Cin);
         return ADK_OK;

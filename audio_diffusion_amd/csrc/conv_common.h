@@ -7,6 +7,7 @@ struct ConvArgs {
     int B, L, P, Lp;
     long long M;
     int nchunks, Cout_alloc, CoutPad, tps, ncot;
+    int gstats;                  // partials per 32-channel group (AdaGN / GroupNorm(C/32, C)) instead of per tile
     unsigned nblk;
 };
 

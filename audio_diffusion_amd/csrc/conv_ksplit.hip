@@ -111,6 +111,9 @@ __global__ __launch_bounds__(256, (TCO * TPOS >= 4 ? 1 : 2)) void conv_ksplit_ke
     TO* yg = reinterpret_cast<TO*>(a.y);
     const TO* rg = reinterpret_cast<const TO*>(a.residual);
     float s1 = 0.f, s2 = 0.f;
+    float gs1[TCO], gs2[TCO];
+#pragma unroll
+    for (int i = 0; i < TCO; ++i) { gs1[i] = 0.f; gs2[i] = 0.f; }
 #pragma unroll
     for (int j = 0; j < TPOS; ++j) {
         const int l = l0 + j * 32 + l31;
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256, (TCO * TPOS >= 4 ? 1 : 2)) void conv_ksplit_ke
                     for (int e = 0; e < 4; ++e) v[e] += rr[e];
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { s1 += v[e]; s2 += v[e] * v[e]; }
+                for (int e = 0; e < 4; ++e) { s1 += v[e]; s2 += v[e] * v[e]; gs1[i] += v[e]; gs2[i] += v[e] * v[e]; }
                 store4(yg + off, v);
             }
         }
@@ -161,7 +164,18 @@ __global__ __launch_bounds__(256, (TCO * TPOS >= 4 ? 1 : 2)) void conv_ksplit_ke
         }
     }
 
-    if (a.partials) {
+    if (a.partials && a.gstats) {                       // [b][g][t * 4 + wave]: this wave's 8 channels of each group
+        const int ngrp = (a.Cout_alloc + 31) >> 5;
+#pragma unroll
+        for (int i = 0; i < TCO; ++i) {
+            const float r1 = wave_sum(gs1[i]), r2 = wave_sum(gs2[i]);
+            const int g = (cobase >> 5) + i;
+            if (lane == 0 && g < ngrp) {
+                float* dst = a.partials + ((((long long)b * ngrp + g) * a.tps + t) * 4 + wave) * 2;
+                dst[0] = r1; dst[1] = r2;
+            }
+        }
+    } else if (a.partials) {
         block_sum2(s1, s2, reinterpret_cast<float*>(smem));     // starts with a barrier: the reads of `red` are done
         if (tid == 0) {
             float* dst = a.partials + ((long long)(b * a.tps + t) * a.ncot + cot) * 2;

@@ -28,6 +28,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
     TO* yg = reinterpret_cast<TO*>(a.y);
     const TO* rg = reinterpret_cast<const TO*>(a.residual);
     float s1 = 0.f, s2 = 0.f;
+    float gs1[TCO], gs2[TCO];                                    // per 32-channel group (ADK_FLAG_GROUP_STATS)
+#pragma unroll
+    for (int i = 0; i < TCO; ++i) { gs1[i] = 0.f; gs2[i] = 0.f; }
 #pragma unroll
     for (int j = 0; j < TPOS; ++j) {
         const int l = l0 + (wpos * TPOS + j) * 32 + l31;
@@ -58,7 +61,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
                             for (int e = 0; e < 4; ++e) v[gg][e] += rr[e];
                         }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { s1 += v[gg][e]; s2 += v[gg][e] * v[gg][e]; }
+                        for (int e = 0; e < 4; ++e) {
+                            s1 += v[gg][e]; s2 += v[gg][e] * v[gg][e];
+                            gs1[i] += v[gg][e]; gs2[i] += v[gg][e] * v[gg][e];
+                        }
                         if constexpr (sizeof(TO) == 4) store4(yg + off, v[gg]);
                     }
                 }
@@ -95,7 +101,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
         }
     }
 
-    if (a.partials) {
+    if (a.partials && a.gstats) {
+        // one (sum, sumsq) pair per (sample, 32-channel group, position tile, wave column): [b][g][t * WPOS + wpos];
+        // no cross-wave step, the consumer (gn_kernel) adds a group's pairs in index order
+        const int ngrp = (a.Cout_alloc + 31) >> 5;
+#pragma unroll
+        for (int i = 0; i < TCO; ++i) {
+            const float r1 = wave_sum(gs1[i]), r2 = wave_sum(gs2[i]);
+            const int g = (cobase >> 5) + wco * TCO + i;
+            if ((tid & 63) == 0 && g < ngrp) {
+                float* dst = a.partials + ((((long long)b * ngrp + g) * a.tps + t) * WPOS + wpos) * 2;
+                dst[0] = r1; dst[1] = r2;
+            }
+        }
+    } else if (a.partials) {
         float* red = reinterpret_cast<float*>(smem);
         block_sum2(s1, s2, red);
         if (tid == 0) {
@@ -414,6 +433,7 @@ void conv_fill_args(const adk_op& op, int BN, int BM, ConvArgs& a)
     a.tps = (op.L + BM - 1) / BM;
     a.ncot = op.CoutPad / BN;
     a.nblk = (unsigned)(op.B * a.tps * a.ncot);
+    a.gstats = (op.flags & ADK_FLAG_GROUP_STATS) ? 1 : 0;
 }
 
 // tile-shape selection (host); adk_conv_cotile / adk_conv_postile / adk_partials_count report it.
@@ -442,6 +462,8 @@ int conv_cotile_used(const adk_op& op) { return conv_tile(op).bn; }
 int conv_partials_count(const adk_op& op)
 {
     const ConvTile t = conv_tile(op);
+    if (op.flags & ADK_FLAG_GROUP_STATS)        // [group][position tile][wave column]: 4 columns in the k-split and
+        return ((op.Cout + 31) / 32) * ((op.L + t.bm - 1) / t.bm) * ((t.ksplit || t.bn == 32) ? 4 : 2);   // Cout<=32 kernels, else 2
     return ((op.L + t.bm - 1) / t.bm) * (op.CoutPad / t.bn);
 }
 

@@ -28,6 +28,35 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinArgs a)
     }
 }
 
+// Wide layers (the stacked AdaGN mappers: ~1e5 outputs): w is given TRANSPOSED, [Cin][Cout], so a wave owns 64
+// consecutive outputs, every weight load is one coalesced 256-byte row segment, the matrix is read once for all
+// samples and a dot product is a sequential fp32 chain over i (no cross-lane step).
+__global__ __launch_bounds__(256) void linear_wt_kernel(const LinArgs a)
+{
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= a.O) return;
+    constexpr int NB = 8;
+    for (int b0 = 0; b0 < a.B; b0 += NB) {
+        float acc[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) acc[u] = 0.f;
+        for (int i = 0; i < a.I; ++i) {
+            const float w = a.w[(long long)i * a.O + o];
+#pragma unroll
+            for (int u = 0; u < NB; ++u)
+                if (b0 + u < a.B) acc[u] = __builtin_fmaf(w, a.x[(long long)(b0 + u) * a.xs + i], acc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u)
+            if (b0 + u < a.B) {
+                float v = acc[u];
+                if (a.bias) v += a.bias[o];
+                if (a.res) v += a.res[(long long)(b0 + u) * a.rs + o];
+                a.y[(long long)(b0 + u) * a.ys + o] = a.gelu ? gelu_erf(v) : v;
+            }
+    }
+}
+
 int launch_linear(const adk_op& op, hipStream_t st)
 {
     LinArgs a;
@@ -36,7 +65,8 @@ int launch_linear(const adk_op& op, hipStream_t st)
     a.y = reinterpret_cast<float*>(op.y);
     a.B = op.B; a.I = op.Cin; a.O = op.Cout; a.xs = op.i0; a.rs = op.i1; a.ys = op.i2;
     a.gelu = (op.flags & ADK_FLAG_GELU) ? 1 : 0;
-    hipLaunchKernelGGL(linear_kernel, dim3((op.Cout + 3) / 4, op.B), dim3(256), 0, st, a);
+    if (op.flags & ADK_FLAG_WT) hipLaunchKernelGGL(linear_wt_kernel, dim3((op.Cout + 255) / 256), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(linear_kernel, dim3((op.Cout + 3) / 4, op.B), dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
 }
 

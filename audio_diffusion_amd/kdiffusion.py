@@ -19,6 +19,7 @@ from torch import nn
 
 from . import _lib
 from .blocks import (AdaGN, DBlock, FourierFeatures, MappingNet, ResModConvBlock, SelfAttentionMod1d, UBlock, UNet)
+from .blocks import fold_down_weight
 from .unet import _Plan, _ceil_to
 
 
@@ -80,79 +81,103 @@ class _KPlan(_Plan):
                 W[o:o + c], W[o + cp:o + cp + c] = w[:c], w[c:]
                 bvec[o:o + c], bvec[o + cp:o + cp + c] = bb[:c], bb[c:]
                 o += 2 * cp
-            return torch.cat([W.reshape(-1), bvec]).to(self.device)
+            return torch.cat([W.t().contiguous().reshape(-1), bvec]).to(self.device)      # [F][total]: ADK_FLAG_WT
         packed = self._dev(("adagn_stack",), stack)
         self.ada_table = self.raw(B * total * 4)
         self._emit(_lib.OP_LINEAR, {"x": ("arena", cond.off), "y": ("arena", self.ada_table.off), "w": ("abs", packed),
-                                    "bias": ("abs", packed + total * F * 4)}, Cin=F, Cout=total, i0=F, i2=total)
+                                    "bias": ("abs", packed + total * F * 4)}, flags=_lib.FLAG_WT, Cin=F, Cout=total,
+                   i0=F, i2=total)
         self.free(cond)
 
     # ---- blocks --------------------------------------------------------------------------------------
-    def adagn(self, x, mod, gelu, out=None):
-        """AdaGN [+ GELU] (blocks/blocks.py:61-64).  Statistics: one gn_stats pass over x."""
+    def adagn(self, x, mod, gelu, out=None, part=None):
+        """AdaGN [+ GELU] (blocks/blocks.py:61-64).  ``part``: statistics of x written by its producer's epilogue
+        (conv with group partials); without them one gn_stats pass over x is emitted.  Frees ``part``."""
         g = mod.num_groups
         cb = 16 if x.f32 else 32
         if g > 1 and (x.C % g or (x.C // g) % cb):
             raise NotImplementedError(f"AdaGN with {g} groups over {x.C} channels: groups must be whole {cb}-channel planes")
-        sop = self._emit(_lib.OP_GN_STATS, {"x": ("arena", x.off)}, L=x.L, Cin=x.C)
-        n = self.lib.adk_partials_count(ctypes.byref(sop))
-        part = self.raw(self.B * n * 8)
-        self._ops[-1][1]["partials_out"] = ("arena", part.off)
         esz = 4 if x.f32 else 2
-        self.meta[-1].update(L=x.L, c=x.C, bytes=float(self.B) * x.C * x.L * esz)
+        if part is None:
+            sop = self._emit(_lib.OP_GN_STATS, {"x": ("arena", x.off)}, L=x.L, Cin=x.C)
+            n = self.lib.adk_partials_count(ctypes.byref(sop))
+            part = self.raw(self.B * n * 8)
+            part.C = n
+            self._ops[-1][1]["partials_out"] = ("arena", part.off)
+            self.meta[-1].update(L=x.L, c=x.C, bytes=float(self.B) * x.C * x.L * esz)
         y = out if out is not None else x
         w_off, b_off = self.ada_off[id(mod)]
         self._emit(_lib.OP_GN_APPLY, {"x": ("arena", x.off), "y": ("arena", y.off), "partials_in": ("arena", part.off),
                                       "gamma": ("arena", self.ada_table.off + 4 * w_off),
                                       "beta": ("arena", self.ada_table.off + 4 * b_off)},
-                   flags=_lib.FLAG_ADA | (_lib.FLAG_GELU if gelu else 0), L=x.L, Cin=x.C, Cout=x.C, n_partials_in=n,
+                   flags=_lib.FLAG_ADA | (_lib.FLAG_GELU if gelu else 0), L=x.L, Cin=x.C, Cout=x.C, n_partials_in=part.C,
                    f0=mod.eps, i0=self.ada_stride, i1=g)
         self.meta[-1].update(L=x.L, c=x.C, bytes=2.0 * self.B * x.C * x.L * esz)
         self.free(part)
         return y
 
-    def res_mod_block(self, blk, key, x, out=None):
-        """ResModConvBlock (blocks/blocks.py:89-101, 48-50).  Does not free x."""
+    @staticmethod
+    def _stats_kw(C):
+        """How a conv producing C channels can hand statistics to a following AdaGN (max(1, C // 32) groups): per
+        32-channel group when C is a multiple of 32, one list for the single group otherwise."""
+        return dict(stats=True, gstats=C % 32 == 0) if (C % 32 == 0 or C < 64) else dict(stats=False)
+
+    def res_mod_block(self, blk, key, x, px=None, out=None, stats=False):
+        """ResModConvBlock (blocks/blocks.py:89-101, 48-50).  Does not free x; frees px.  Returns (y, stats of y)."""
         a1, c1, a2, c2 = blk.main[0], blk.main[2], blk.main[4], blk.main[6]
-        h = self.adagn(x, a1, True, out=self.tensor(x.C, x.L))
-        raw1, _ = self.conv(h, key + "main.2", c1.weight, c1.bias, blk.c_mid)
+        h = self.adagn(x, a1, True, out=self.tensor(x.C, x.L), part=px)
+        raw1, p1 = self.conv(h, key + "main.2", c1.weight, c1.bias, blk.c_mid, **self._stats_kw(blk.c_mid))
         self.free(h)
-        self.adagn(raw1, a2, True)
+        self.adagn(raw1, a2, True, part=p1)
         r = x
         if isinstance(blk.skip, nn.Conv1d):
             r, _ = self.conv(x, key + "skip", blk.skip.weight, None, blk.c_out)
-        y, _ = self.conv(raw1, key + "main.6", c2.weight, c2.bias, blk.c_out, residual=r, out=out)
+        kw = self._stats_kw(blk.c_out) if stats else {}
+        y, py = self.conv(raw1, key + "main.6", c2.weight, c2.bias, blk.c_out, residual=r, out=out, **kw)
         self.free(raw1)
         if r is not x:
             self.free(r)
-        return y
+        return y, py
 
-    def attention_mod(self, att, key, x, out=None):
-        """SelfAttentionMod1d (blocks/blocks.py:134-144).  Frees x."""
-        n = self.adagn(x, att.norm_in, False, out=self.tensor(x.C, x.L))
+    def attention_mod(self, att, key, x, px=None, out=None, stats=False):
+        """SelfAttentionMod1d (blocks/blocks.py:134-144).  Frees x and px.  Returns (y, stats of y)."""
+        n = self.adagn(x, att.norm_in, False, out=self.tensor(x.C, x.L), part=px)
         qkv, _ = self.conv(n, key + "qkv_proj", att.qkv_proj.weight, att.qkv_proj.bias, 3 * x.C)
         self.free(n)
         y = self.tensor(x.C, x.L)
         self._emit(_lib.OP_ATTN, {"x": ("arena", qkv.off), "y": ("arena", y.off)}, L=x.L, Cin=x.C, i0=x.C // att.n_head)
         self.meta[-1].update(L=x.L, c=x.C, attn_flops=4.0 * x.L * x.L * x.C * self.B)
         self.free(qkv)
-        o, _ = self.conv(y, key + "out_proj", att.out_proj.weight, att.out_proj.bias, x.C, residual=x, out=out)
+        kw = self._stats_kw(x.C) if stats else {}
+        o, po = self.conv(y, key + "out_proj", att.out_proj.weight, att.out_proj.bias, x.C, residual=x, out=out, **kw)
         self.free(y, x)
-        return o
+        return o, po
 
-    def layers(self, mods, keys, x, final_out=None, keep_input=False):
-        """A run of ResModConvBlock / SelfAttentionMod1d modules; frees intermediates (and x unless keep_input)."""
-        cur, owned = x, not keep_input
+    def layers(self, mods, keys, x, px=None, final_out=None, keep_input=False, stats_out=False):
+        """A run of ResModConvBlock / SelfAttentionMod1d modules; frees intermediates (and x unless keep_input).
+        Every module's output statistics come out of its last conv's epilogue for the next module's AdaGN."""
+        cur, pcur, owned = x, px, not keep_input
         for j, (mod, key) in enumerate(zip(mods, keys)):
-            out = final_out if j == len(mods) - 1 else None
+            last = j == len(mods) - 1
+            out = final_out if last else None
             if isinstance(mod, ResModConvBlock):
-                y = self.res_mod_block(mod, key, cur, out=out)
+                y, py = self.res_mod_block(mod, key, cur, pcur, out=out, stats=stats_out or not last)
                 if owned:
                     self.free(cur)
             else:
-                y = self.attention_mod(mod, key, cur, out=out)         # frees cur itself
-            cur, owned = y, True
-        return cur
+                y, py = self.attention_mod(mod, key, cur, pcur, out=out, stats=stats_out or not last)     # frees cur itself
+            cur, pcur, owned = y, py, True
+        return (cur, pcur) if stats_out else cur
+
+    def down(self, mod, key, x):
+        """Downsample1d_2 (blocks/blocks.py:214-226) as space_to_depth + folded 3-tap conv (see unet.py), whose epilogue
+        also hands the statistics of its output to the first AdaGN of the level."""
+        f = mod.stride[0]
+        folded = self.shuffle(x, f, True)
+        d, p = self.conv(folded, key + f"fold{f}", fold_down_weight(mod.weight.detach().float().cpu(), f), mod.bias,
+                         mod.out_channels, **self._stats_kw(mod.out_channels))
+        self.free(folded)
+        return d, p
 
     def _build(self):
         m, B = self.model, self.B
@@ -182,20 +207,23 @@ class _KPlan(_Plan):
             mods = list(blk)
             keys = [f"u_net.d_blocks.{j}.{k}." for k in range(len(mods))]
             if j == 0:
-                h, _ = self.conv(x0, "proj_in", m.proj_in.weight, m.proj_in.bias, ch[0])
+                h, ph = self.conv(x0, "proj_in", m.proj_in.weight, m.proj_in.bias, ch[0], **self._stats_kw(ch[0]))
                 self.free(x0)
                 owned = True
             else:
-                h, owned = cur, False                                     # the skip of level j-1: stays alive
+                h, ph, owned = cur, None, False                           # the skip of level j-1: stays alive
                 if blk.ratio > 1:
-                    h = self.resample_down(mods[0], keys[0], h)
+                    h, ph = self.down(mods[0], keys[0], h)
                     mods, keys, owned = mods[1:], keys[1:], True
             if j < n - 1:
                 cats[j] = self.tensor(2 * ch[j], h.L)
                 dst = self.half(cats[j], 1, ch[j])
             else:
                 dst = None
-            cur = self.layers(mods, keys, h, final_out=dst, keep_input=not owned)
+            if j < n - 1:
+                cur = self.layers(mods, keys, h, ph, final_out=dst, keep_input=not owned)
+            else:                                                         # deepest level: feeds the up path directly
+                cur, pdeep = self.layers(mods, keys, h, ph, keep_input=not owned, stats_out=True)
         # up path
         x = cur
         for i in range(n):
@@ -208,12 +236,12 @@ class _KPlan(_Plan):
                 mods, keys_l = mods[:-1], keys[:-1]
             else:
                 keys_l = keys
-            src = x if i == 0 else cats[j]
+            src, psrc = (x, pdeep) if i == 0 else (cats[j], None)
             dst = self.half(cats[j - 1], 0, ch[j - 1]) if j > 0 else None
             if up is None:
-                y = self.layers(mods, keys_l, src, final_out=dst)
+                y = self.layers(mods, keys_l, src, psrc, final_out=dst)
             else:
-                u = self.layers(mods, keys_l, src)
+                u = self.layers(mods, keys_l, src, psrc)
                 self.resample_up(up, keys[-1], u, dst)
                 self.free(u)
                 y = dst

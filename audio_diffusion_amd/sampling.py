@@ -204,3 +204,83 @@ def _sample(model, x, steps, eta, warp, extra_args):
         if auto:
             model.compute_dtype = prev
     return pred
+
+
+# ---- Karras-ODE samplers for the k-diffusion denoiser family ------------------------------------------
+# Host-side loops around ``denoiser(x, sigma)`` (kdiffusion.Denoiser / AudioDenoiserModel): the schedules and the
+# per-step updates are a handful of elementwise torch ops on the device; all the work is in the denoiser call.
+def get_sigmas_karras(n, sigma_min, sigma_max, rho=7., device="cpu"):
+    """Karras et al. (2022) noise schedule with a trailing 0 (reference diffusion/inference.py:60-67)."""
+    lo, hi = sigma_min ** (1 / rho), sigma_max ** (1 / rho)
+    sig = (hi + torch.linspace(0, 1, n) * (lo - hi)) ** rho
+    return torch.cat([sig, sig.new_zeros([1])]).to(device)
+
+
+def get_sigmas_exponential(n, sigma_min, sigma_max, device="cpu"):
+    """Log-linear noise schedule with a trailing 0 (reference diffusion/inference.py:70-73)."""
+    sig = torch.linspace(math.log(sigma_max), math.log(sigma_min), n, device=device).exp()
+    return torch.cat([sig, sig.new_zeros([1])])
+
+
+def to_d(x, sigma, denoised):
+    """ODE derivative dx/dsigma from a denoiser output (reference diffusion/inference.py:94-96)."""
+    return (x - denoised) / sigma.reshape(sigma.shape + (1,) * (x.ndim - sigma.ndim))
+
+
+@torch.no_grad()
+def sample_heun(model, x, sigmas, extra_args=None, callback=None, disable=None, second_order=True, s_churn=0.):
+    """Heun (2nd order) / Euler sampler of the Karras ODE, drop-in for reference diffusion/inference.py:99-122
+    (``disable`` is accepted for signature parity; there is no progress bar)."""
+    extra_args = extra_args or {}
+    ones = x.new_ones([x.shape[0]])
+    n = len(sigmas) - 1
+    gamma = min(s_churn / n, 2 ** 0.5 - 1) if n else 0.
+    for i in range(n):
+        noise = torch.randn_like(x)                       # drawn every step like the reference (keeps its RNG stream)
+        s_hat = sigmas[i] * (gamma + 1)
+        if gamma > 0:
+            x = x + noise * (s_hat ** 2 - sigmas[i] ** 2) ** 0.5
+        den = model(x, s_hat * ones, **extra_args)
+        d = to_d(x, s_hat, den)
+        if callback is not None:
+            callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": s_hat, "denoised": den})
+        dt = sigmas[i + 1] - s_hat
+        if sigmas[i + 1] == 0 or not second_order:
+            x = x + d * dt                                # Euler step (always the last one)
+            continue
+        x_mid = x + d * dt
+        d_mid = to_d(x_mid, sigmas[i + 1], model(x_mid, sigmas[i + 1] * ones, **extra_args))
+        x = x + (d + d_mid) / 2 * dt
+    return x
+
+
+def _lms_coeff(order, t, i, j):
+    """Integral of the j-th Lagrange basis polynomial over [t_i, t_{i+1}] (reference diffusion/inference.py:125-135)."""
+    from scipy import integrate
+    if order - 1 > i:
+        raise ValueError(f"Order {order} too high for step {i}")
+
+    def basis(tau):
+        p = 1.
+        for k in range(order):
+            if k != j:
+                p *= (tau - t[i - k]) / (t[i - j] - t[i - k])
+        return p
+    return integrate.quad(basis, t[i], t[i + 1], epsrel=1e-4)[0]
+
+
+@torch.no_grad()
+def sample_lms(model, x, sigmas, extra_args=None, callback=None, disable=None, order=4):
+    """Linear multistep sampler, drop-in for reference diffusion/inference.py:138-154."""
+    extra_args = extra_args or {}
+    ones = x.new_ones([x.shape[0]])
+    t = sigmas.cpu()
+    hist = []
+    for i in range(len(sigmas) - 1):
+        den = model(x, sigmas[i] * ones, **extra_args)
+        hist = (hist + [to_d(x, sigmas[i], den)])[-order:]
+        if callback is not None:
+            callback({"x": x, "i": i, "sigma": sigmas[i], "sigma_hat": sigmas[i], "denoised": den})
+        k = min(i + 1, order)
+        x = x + sum(_lms_coeff(k, t, i, j) * d for j, d in zip(range(k), reversed(hist)))
+    return x

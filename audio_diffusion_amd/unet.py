@@ -152,7 +152,7 @@ class _Plan:
         self.meta.append({"kind": kind})
         return op
 
-    def conv(self, x, key, w, bias, Cout, out=None, residual=None, stats=False, out_f32=False):
+    def conv(self, x, key, w, bias, Cout, out=None, residual=None, stats=False, out_f32=False, gstats=False):
         taps = w.shape[2]
         bn = self.lib.adk_conv_cotile(self.adk_dtype, Cout, x.L)
         cout_pad = _ceil_to(Cout, bn)
@@ -165,6 +165,8 @@ class _Plan:
         if residual is not None:
             ptrs["residual"] = ("arena", residual.off)
         flags = _lib.FLAG_OUT_F32 if (out_f32 and self.dtype != torch.float32) else 0
+        if stats and gstats:              # one partial list per 32-channel group (AdaGN consumers, kdiffusion.py)
+            flags |= _lib.FLAG_GROUP_STATS
         op = self._emit(_lib.OP_CONV, ptrs, flags=flags, L=x.L, Cin=cin_alloc, Cout=Cout, CoutPad=cout_pad, taps=taps)
         self.meta[-1].update(taps=taps, L=x.L, cin=w.shape[1], cout=Cout, cotile=self.lib.adk_conv_cotile_used(ctypes.byref(op)),
                              postile=self.lib.adk_conv_postile(ctypes.byref(op)),

@@ -66,6 +66,10 @@ enum {
                                    (row stride i0 floats) and the scale is gamma + 1                */
 #define ADK_FLAG_LOG 16u        /* FOURIER: embed log(sigma)/4 instead of sigma                    */
 #define ADK_FLAG_NO_EMBED 32u   /* PACK_INPUT: no timestep-embedding channels ([x | cond] only)    */
+#define ADK_FLAG_WT 128u         /* LINEAR: w is given transposed, [Cin][Cout] (wide layers: coalesced, read once) */
+#define ADK_FLAG_GROUP_STATS 64u /* CONV: partials_out holds one (sum,sumsq) list per 32-channel group,
+                                   [B][ceil(Cout/32)][adk_partials_count / groups][2], for a following
+                                   AdaGN / GroupNorm(C/32, C) (blocks/blocks.py:63, 93, 97)          */
 
 /* One flat descriptor for every op kind; unused fields are 0/NULL.  Field use per kind is
  * documented at the matching adk_* entry point below (same names). */
@@ -153,7 +157,8 @@ int adk_adagn_apply(int dtype, uint32_t flags, int B, int L, int P, int C, int g
 
 /* Replaces nn.Linear on per-sample rows (MappingNet blocks/blocks.py:292-301, mapping_cond and the AdaGN mappers
  * blocks/blocks.py:59,62): y[b][o] = act(sum_i w[o][i] x[b][i] + bias[o] + residual[b][o]), all f32, w row-major
- * [Cout][Cin]; bias/residual may be NULL; act = exact GELU with ADK_FLAG_GELU; strides in floats. */
+ * [Cout][Cin] (or [Cin][Cout] with ADK_FLAG_WT, the fast form for wide layers); bias/residual may be NULL;
+ * act = exact GELU with ADK_FLAG_GELU; strides in floats. */
 int adk_linear(uint32_t flags, int B, int Cin, int Cout, const float *x, int x_stride, const float *w, const float *bias,
                const float *residual, int res_stride, float *y, int y_stride, void *stream);
 

@@ -25,6 +25,10 @@ CONFIGS = {
                 n_attn_layers=1), 4, 262144, torch.bfloat16),
     "4": (dict(io_channels=2, pqmf_bands=32, depth=10, c_mults=[256, 256] + [512] * 8, n_attn_layers=2),
           16, 131072, torch.bfloat16),
+    # model_configs/k_audio_uncond_long_1.json (the k-diffusion consumer of config 3b): AudioDenoiserModel behind the
+    # Karras Denoiser, input = 16 PQMF bands x 2 channels of a 524288-sample clip
+    "k-audio": (dict(c_in=32, feats_in=128, depths=[2, 2, 2, 3, 3, 3, 4, 4], channels=[256, 256, 512, 512, 512, 512, 512, 512],
+                     self_attn_depths=[False] * 5 + [True] * 3, strides=[4, 4, 4, 2, 2, 2, 2]), 4, 524288, torch.bfloat16),
 }
 
 
@@ -50,13 +54,23 @@ def main():
     for name in names:
         kw, B, T, dtype = CONFIGS[name]
         torch.manual_seed(0)
-        m = A.DiffusionAttnUnet1D(**kw).to(dev).eval()
-        m.compute_dtype = dtype
-        x = torch.randn(B, 2, T, device=dev)
-        t = torch.full((B,), 0.5, device=dev)
-        plan = m.plan_for(B, T, dtype, dev)
-        out = torch.empty_like(x)
-        plan.bind(x.data_ptr(), t.data_ptr(), out.data_ptr())
+        if name == "k-audio":
+            m = A.AudioDenoiserModel(**kw).to(dev).eval()
+            x = torch.randn(B, 32, T // 16, device=dev)
+            t = torch.full((B,), 0.5, device=dev)
+            sc = [s.contiguous() for s in A.Denoiser(m, 0.25).get_scalings(t)]
+            plan = m.plan_for(B, T // 16, dtype, dev, scaled=True)
+            out = torch.empty_like(x)
+            plan.bind_named(input=x.data_ptr(), t=t.data_ptr(), output=out.data_ptr(), cskip=sc[0].data_ptr(),
+                            cout=sc[1].data_ptr(), cin=sc[2].data_ptr())
+        else:
+            m = A.DiffusionAttnUnet1D(**kw).to(dev).eval()
+            m.compute_dtype = dtype
+            x = torch.randn(B, 2, T, device=dev)
+            t = torch.full((B,), 0.5, device=dev)
+            plan = m.plan_for(B, T, dtype, dev)
+            out = torch.empty_like(x)
+            plan.bind(x.data_ptr(), t.data_ptr(), out.data_ptr())
         st = torch.cuda.current_stream(dev)
         ms = timed(lambda: plan.run(st.cuda_stream), a.reps)
         flops = sum(mt.get("flops", 0.0) for mt in plan.meta)

@@ -292,7 +292,18 @@ def tier_kdiff():
             # reference is called one sample at a time (per-sample scaling is what it computes there)
             dn = Denoiser(m, sigma_data=sigma_data)
             d = torch.cat([dn(x[b:b + 1], sigma[b:b + 1], **{k: v[b:b + 1] for k, v in extra.items()}) for b in range(2)])
-        npz(name + ".npz", seed=np.int64(60 + i), x=x, sigma=sigma, y=y, y_nolog=y_nolog, denoised=d, sigma_data=np.float32(sigma_data),
+        samp = {}
+        if name == "kdiff_tiny":            # the reference's own samplers around its own Denoiser (batch 1: see above)
+            from diffusion import inference as INF
+            sig_k = INF.get_sigmas_karras(6, 1e-2, 3.0, rho=9.)
+            sig_e = INF.get_sigmas_exponential(5, 1e-2, 3.0)
+            x1 = x[:1] * 3.0
+            with torch.no_grad():
+                samp = {"samp/sigmas_karras": sig_k, "samp/sigmas_exp": sig_e, "samp/x": x1,
+                        "samp/heun": INF.sample_heun(dn, x1, sig_k, disable=True),
+                        "samp/euler": INF.sample_heun(dn, x1, sig_e, disable=True, second_order=False),
+                        "samp/lms": INF.sample_lms(dn, x1, sig_k, disable=True, order=3)}
+        npz(name + ".npz", seed=np.int64(60 + i), x=x, sigma=sigma, y=y, **samp, y_nolog=y_nolog, denoised=d, sigma_data=np.float32(sigma_data),
             cfg=np.bytes_(json.dumps(kw).encode()), **{"extra/" + k: v for k, v in extra.items()}, **sd_arrays(m.state_dict()))
 
 

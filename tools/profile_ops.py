@@ -14,7 +14,7 @@ import audio_diffusion_amd as A
 from audio_diffusion_amd import _lib
 
 NAMES = {1: "conv", 2: "gn_apply", 3: "gn_stats", 4: "fir_down", 5: "fir_up", 6: "attn", 7: "pack", 8: "unpack",
-         9: "pqmf_a", 10: "pqmf_s"}
+         9: "pqmf_a", 10: "pqmf_s", 14: "s2d", 15: "d2s", 16: "linear", 17: "fourier"}
 
 
 def main():
@@ -23,16 +23,28 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--T", type=int, default=65536)
+    ap.add_argument("--model", default="uncond", help="uncond (config 2) | k-audio (k_audio_uncond_long_1.json, B=4, 32 x 32768)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     torch.manual_seed(0)
-    m = A.DiffusionAttnUnet1D(n_attn_layers=4).to(dev).eval()
-    plan = m.plan_for(a.batch, a.T, dtype, dev)
-    x = torch.randn(a.batch, 2, a.T, device=dev)
-    t = torch.ones(a.batch, device=dev)
-    out = torch.empty_like(x)
-    plan.bind(x.data_ptr(), t.data_ptr(), out.data_ptr())
+    if a.model == "k-audio":
+        a.batch = 4 if a.batch == 16 else a.batch
+        m = A.AudioDenoiserModel(c_in=32, feats_in=128, depths=[2, 2, 2, 3, 3, 3, 4, 4],
+                                 channels=[256, 256, 512, 512, 512, 512, 512, 512],
+                                 self_attn_depths=[False] * 5 + [True] * 3, strides=[4, 4, 4, 2, 2, 2, 2]).to(dev).eval()
+        plan = m.plan_for(a.batch, 32768, dtype, dev)
+        x = torch.randn(a.batch, 32, 32768, device=dev)
+        t = torch.ones(a.batch, device=dev)
+        out = torch.empty_like(x)
+        plan.bind_named(input=x.data_ptr(), t=t.data_ptr(), output=out.data_ptr())
+    else:
+        m = A.DiffusionAttnUnet1D(n_attn_layers=4).to(dev).eval()
+        plan = m.plan_for(a.batch, a.T, dtype, dev)
+        x = torch.randn(a.batch, 2, a.T, device=dev)
+        t = torch.ones(a.batch, device=dev)
+        out = torch.empty_like(x)
+        plan.bind(x.data_ptr(), t.data_ptr(), out.data_ptr())
     st = torch.cuda.current_stream(dev)
     sz = ctypes.sizeof(_lib.AdkOp)
     ms = [0.0] * plan.n_ops

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256) void linear_wt_kernel(const LinArgs a)
         float acc[NB];
 #pragma unroll
         for (int u = 0; u < NB; ++u) acc[u] = 0.f;
-        for (int i = 0; i < a.I; ++i) {
+#pragma unroll 16
+        for (int i = 0; i < a.I; ++i) {                   // 16 independent weight loads in flight per thread
             const float w = a.w[(long long)i * a.O + o];
 #pragma unroll
             for (int u = 0; u < NB; ++u)

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libadk.so")
+LIB_PATH = os.environ.get("ADK_LIB") or os.path.join(_HERE, "libadk.so")     # ADK_LIB: A/B runs against another build
 
 ADK_F32, ADK_BF16 = 0, 1
 
@@ -18,6 +18,7 @@ OP_DDIM_UPDATE, OP_STEP_ADVANCE, OP_AUDIO_TO_INT16, OP_SPACE_TO_DEPTH, OP_DEPTH_
 OP_LINEAR, OP_FOURIER = 16, 17
 
 FLAG_GELU, FLAG_OUT_F32, FLAG_NOISE, FLAG_ADA, FLAG_LOG, FLAG_NO_EMBED, FLAG_GROUP_STATS, FLAG_WT = 1, 2, 4, 8, 16, 32, 64, 128
+FLAG_CAUSAL, FLAG_ELU = 256, 512
 
 
 class AdkOp(C.Structure):

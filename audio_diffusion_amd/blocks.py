@@ -142,7 +142,7 @@ def fold_down_weight(w, factor):
     return out.reshape(co, f * c, 3)
 
 
-def fold_up_weight(wt, bias, factor):
+def fold_up_weight(wt, bias, factor, pad=None):
     """ConvTranspose1d(k = 2f, stride f, padding pad = f//2 + f%2, output_padding f%2) == 3-tap stride-1 conv
     producing f phases per input position, y[co][j*f + s] = z[s*Co + co][j]:  with r = (s + pad) mod f,
         r >= pad:  z[s][j] = wt[:, :, r + f]^T x[j - 1] + wt[:, :, r]^T x[j]
@@ -151,7 +151,8 @@ def fold_up_weight(wt, bias, factor):
     c, co, k = wt.shape
     f = factor
     assert k == 2 * f
-    pad = f // 2 + f % 2
+    if pad is None:                # Upsample1d_2's padding; pad = 0: CausalConvTranspose1d (soundstream.py), whose
+        pad = f // 2 + f % 2       # trimmed tail [..., :-f] leaves exactly y[j*f + s] = W[s]^T x[j] + W[s+f]^T x[j-1]
     out = wt.new_zeros(f, co, c, 3)
     for s in range(f):
         r = (s + pad) % f

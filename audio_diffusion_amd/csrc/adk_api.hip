@@ -56,7 +56,13 @@ static int validate(const adk_op& o)
         if ((rc = check_geo(o, "conv1d"))) return rc;
         const int cb = cb_of(o.dtype);
         REQUIRE(o.taps == 1 || o.taps == 3 || o.taps == 5 || o.taps == 7, "conv1d: taps=%d unsupported (1, 3, 5 or 7)", o.taps);
-        REQUIRE(o.P >= o.taps / 2, "conv1d: halo P=%d < taps/2=%d", o.P, o.taps / 2);
+        const int dil = o.i0 > 1 ? o.i0 : 1;
+        REQUIRE(dil == 1 || (o.taps == 7 && (dil == 3 || dil == 9)), "conv1d: dilation %d unsupported (1; 3 or 9 with 7 taps)", dil);
+        REQUIRE(o.taps != 5 || (!(o.flags & (ADK_FLAG_CAUSAL | ADK_FLAG_ELU | ADK_FLAG_GROUP_STATS)) && dil == 1),
+                "conv1d: causal / ELU / group-statistics convs are built for 1, 3 and 7 taps");
+        const int reach = (o.flags & ADK_FLAG_CAUSAL) ? (o.taps - 1) * dil : (o.taps / 2) * dil;
+        REQUIRE(o.P >= reach, "conv1d: halo P=%d < %d rows of padding (taps=%d, dilation=%d%s)", o.P, reach, o.taps, dil,
+                (o.flags & ADK_FLAG_CAUSAL) ? ", causal" : "");
         REQUIRE(o.Cin >= cb && o.Cin % cb == 0, "conv1d: Cin=%d not a multiple of %d", o.Cin, cb);
         REQUIRE(o.Cout >= 1, "conv1d: Cout=%d", o.Cout);
         const int bn = conv_cotile(o.Cout);

@@ -8,6 +8,7 @@ struct ConvArgs {
     long long M;
     int nchunks, Cout_alloc, CoutPad, tps, ncot;
     int gstats;                  // partials per 32-channel group (AdaGN / GroupNorm(C/32, C)) instead of per tile
+    int shift, dil, elu;         // tap k reads row pos - shift + k*dil (centred: shift = taps/2; causal: (taps-1)*dil); ELU epilogue
     unsigned nblk;
 };
 
@@ -28,6 +29,9 @@ template <> struct Mma<float> {
         c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], c, 0, 0, 0);
     }
 };
+
+// nn.ELU (alpha = 1), applied by the conv epilogues of the SoundStream decoder (autoencoders/soundstream.py:46,94-110)
+__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : expm1f(v); }
 
 __device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -51,3 +55,4 @@ struct ConvTile { int bn, bm; bool ksplit; };
 ConvTile conv_tile(const adk_op& op);
 void conv_fill_args(const adk_op& op, int BN, int BM, ConvArgs& a);
 int launch_conv_ksplit(const adk_op& op, hipStream_t st);
+int launch_conv_ext(const adk_op& op, hipStream_t st);      // conv_mfma_ext.hip

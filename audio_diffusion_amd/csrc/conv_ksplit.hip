@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256, (TCO * TPOS >= 4 ? 1 : 2)) void conv_ksplit_ke
     const int b = (int)(r1 / (unsigned)a.tps);
     const int cobase = cot * BN;
     const int l0 = t * BM;
-    const int mrow0 = b * a.Lp + a.P + l0 - TAPS / 2;          // >= 0: P >= TAPS/2 (validated on the host)
+    const int mrow0 = b * a.Lp + a.P + l0 - a.shift;           // >= 0: P >= shift (validated on the host)
+    const int dil = a.dil;
     const int mlast = (int)a.M - 1;
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256, (TCO * TPOS >= 4 ? 1 : 2)) void conv_ksplit_ke
             _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                    \
                 fa[D_][TAP_][i][s] = *reinterpret_cast<const Frag*>(wp_ + i * 2048 + s * 32);                \
         _Pragma("unroll") for (int j = 0; j < TPOS; ++j) {                                                   \
-            int row_ = mrow0 + j * 32 + l31 + (TAP_);                                                        \
+            int row_ = mrow0 + j * 32 + l31 + (TAP_) * dil;                                                  \
             row_ = row_ > mlast ? mlast : row_;          /* rows past the tensor only feed masked columns */ \
             _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                    \
                 fb[D_][TAP_][j][s] = *reinterpret_cast<const Frag*>(xp_ + (long long)row_ * 64 + s * 32);    \
@@ -139,6 +140,10 @@ __global__ __launch_bounds__(256, (TCO * TPOS >= 4 ? 1 : 2)) void conv_ksplit_ke
                     load4(rg + off, rr);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += rr[e];
+                }
+                if (a.elu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = elu1(v[e]);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { s1 += v[e]; s2 += v[e] * v[e]; gs1[i] += v[e]; gs2[i] += v[e] * v[e]; }

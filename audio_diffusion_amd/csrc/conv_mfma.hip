@@ -12,414 +12,7 @@
 //   bf16: v_mfma_f32_32x32x16_bf16 (fp32 accumulate);  f32: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain).
 // Epilogue: + bias, (+ residual), per-tile (sum, sumsq) partials for the following GroupNorm(1,C)
 // (deterministic: fixed-order tree, no atomics), halo rows of the output zeroed by the edge tiles.
-#include "conv_common.h"
-
-template <typename TO, int BN, int BM, int WPOS, int TCO, int TPOS>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TCO][TPOS], unsigned char* smem,
-                                              int b, int t, int cot, int cobase, int l0, int tid, int l31, int h,
-                                              int wco, int wpos)
-{
-    constexpr int CBO = ElemTraits<TO>::CB;
-    // ---- epilogue: lane (l31, h) holds D[co = 8g + 4h + e][pos = l31] in acc[..][4g + e] ----
-    // bf16 output: the two half-waves hold the two 8-byte halves of one 16-byte piece, so channel groups are
-    // processed in pairs (g, g+1) and exchanged with v_permlane32_swap: lanes h=0 then store channels
-    // 8g..8g+7, lanes h=1 channels 8g+8..8g+15, as ONE 16-byte store each (half the store instructions:
-    // the tail of this kernel is store-issue bound, not bandwidth bound).
-    TO* yg = reinterpret_cast<TO*>(a.y);
-    const TO* rg = reinterpret_cast<const TO*>(a.residual);
-    float s1 = 0.f, s2 = 0.f;
-    float gs1[TCO], gs2[TCO];                                    // per 32-channel group (ADK_FLAG_GROUP_STATS)
-#pragma unroll
-    for (int i = 0; i < TCO; ++i) { gs1[i] = 0.f; gs2[i] = 0.f; }
-#pragma unroll
-    for (int j = 0; j < TPOS; ++j) {
-        const int l = l0 + (wpos * TPOS + j) * 32 + l31;
-        const bool lvalid = l < a.L;
-        const long long m = (long long)b * a.Lp + a.P + l;
-#pragma unroll
-        for (int i = 0; i < TCO; ++i) {
-            const int co32 = cobase + (wco * TCO + i) * 32;
-            const bool ok = lvalid && co32 < a.Cout_alloc;      // Cout_alloc is a multiple of 32 when TO = bf16
-#pragma unroll
-            for (int g0 = 0; g0 < 4; g0 += 2) {
-                float v[2][4];
-#pragma unroll
-                for (int gg = 0; gg < 2; ++gg) {
-                    const int co = co32 + 8 * (g0 + gg) + 4 * h;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[gg][e] = acc[i][j][4 * (g0 + gg) + e];
-                    if (a.bias) {
-                        const float4 bb = *reinterpret_cast<const float4*>(a.bias + co);
-                        v[gg][0] += bb.x; v[gg][1] += bb.y; v[gg][2] += bb.z; v[gg][3] += bb.w;
-                    }
-                    if (lvalid && co < a.Cout_alloc) {
-                        const long long off = (((long long)(co / CBO) * a.M + m) * CBO) + (co % CBO);
-                        if (rg) {
-                            float rr[4];
-                            load4(rg + off, rr);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[gg][e] += rr[e];
-                        }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            s1 += v[gg][e]; s2 += v[gg][e] * v[gg][e];
-                            gs1[i] += v[gg][e]; gs2[i] += v[gg][e] * v[gg][e];
-                        }
-                        if constexpr (sizeof(TO) == 4) store4(yg + off, v[gg]);
-                    }
-                }
-                if constexpr (sizeof(TO) == 2) {
-                    uint32_t ax = pack_bf16x2(v[0][0], v[0][1]), ay = pack_bf16x2(v[0][2], v[0][3]);
-                    uint32_t bx = pack_bf16x2(v[1][0], v[1][1]), by = pack_bf16x2(v[1][2], v[1][3]);
-                    // swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second (all lanes active here)
-                    const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
-                    const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-                    if (ok) {
-                        const int co = co32 + 8 * g0 + 8 * h;   // h=0: [own g0 | partner's g0], h=1: [partner's g0+1 | own g0+1]
-                        const long long off = (((long long)(co / CBO) * a.M + m) * CBO) + (co % CBO);
-                        *reinterpret_cast<uint4*>(yg + off) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
-                    }
-                }
-            }
-        }
-    }
-
-    // halo rows of the output: zeroed by the first / last tile of each sample
-    if (t == 0 || t == a.tps - 1) {
-        const int plane0 = cobase / CBO;
-        const int cend = cobase + BN < a.Cout_alloc ? cobase + BN : a.Cout_alloc;
-        const int nplanes = cend / CBO - plane0;
-        const int per = a.P * 4;
-        const uint4 z = make_uint4(0, 0, 0, 0);
-        unsigned char* yb = reinterpret_cast<unsigned char*>(a.y);
-        for (int p = tid; p < nplanes * per; p += (int)blockDim.x) {
-            const int pl = plane0 + p / per, rem = p % per, row = rem >> 2, q = rem & 3;
-            const long long mh = (long long)b * a.Lp + row;
-            if (t == 0) *reinterpret_cast<uint4*>(yb + ((long long)pl * a.M + mh) * 64 + q * 16) = z;
-            if (t == a.tps - 1)
-                *reinterpret_cast<uint4*>(yb + ((long long)pl * a.M + mh + a.P + a.L) * 64 + q * 16) = z;
-        }
-    }
-
-    if (a.partials && a.gstats) {
-        // one (sum, sumsq) pair per (sample, 32-channel group, position tile, wave column): [b][g][t * WPOS + wpos];
-        // no cross-wave step, the consumer (gn_kernel) adds a group's pairs in index order
-        const int ngrp = (a.Cout_alloc + 31) >> 5;
-#pragma unroll
-        for (int i = 0; i < TCO; ++i) {
-            const float r1 = wave_sum(gs1[i]), r2 = wave_sum(gs2[i]);
-            const int g = (cobase >> 5) + wco * TCO + i;
-            if ((tid & 63) == 0 && g < ngrp) {
-                float* dst = a.partials + ((((long long)b * ngrp + g) * a.tps + t) * WPOS + wpos) * 2;
-                dst[0] = r1; dst[1] = r2;
-            }
-        }
-    } else if (a.partials) {
-        float* red = reinterpret_cast<float*>(smem);
-        block_sum2(s1, s2, red);
-        if (tid == 0) {
-            float* dst = a.partials + ((long long)(b * a.tps + t) * a.ncot + cot) * 2;
-            dst[0] = s1; dst[1] = s2;
-        }
-    }
-}
-
-// LDS image: plain 64-byte rows filled by LDS-DMA (global_load_lds_dwordx4: 1 KiB = 16 rows per wave
-// instruction, destination lane-linear), XOR-swizzled through the SOURCE address: the 16-byte piece p of
-// row r is stored in slot p ^ ((r >> 2) & 3), which makes every ds_read_b128 fragment read conflict-free
-// (a 16-lane read group then touches 16 distinct 16-byte slots of the 256-byte bank row).
-__device__ __forceinline__ void glds16(const unsigned char* src, unsigned char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-template <typename T, typename TO, int TAPS, int WCO, int WPOS, int TCO, int TPOS>
-__global__ __launch_bounds__(256, 2) void conv_mfma_simple_kernel(const ConvArgs a)
-{
-    constexpr int BN = WCO * TCO * 32;           // output channels per block (MFMA rows)
-    constexpr int BM = WPOS * TPOS * 32;         // positions per block (MFMA cols)
-    constexpr int XROWS = BM + TAPS - 1;
-    constexpr int NXI = (XROWS + 15) / 16;       // 1-KiB LDS-DMA instructions for the X tile
-    constexpr int NWI = TAPS * BN / 16;          // ... for the W tile
-    static_assert(WCO * WPOS == 4, "4 waves per block");
-    static_assert(BN % 32 == 0, "co tile");
-    typedef typename Mma<T>::Frag Frag;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* xs = smem;
-    unsigned char* ws = smem + NXI * 1024;
-
-    const unsigned lid = xcd_remap(blockIdx.x, a.nblk);
-    const int cot = (int)(lid % (unsigned)a.ncot);
-    const unsigned r1 = lid / (unsigned)a.ncot;
-    const int t = (int)(r1 % (unsigned)a.tps);
-    const int b = (int)(r1 / (unsigned)a.tps);
-    const int cobase = cot * BN;
-    const int l0 = t * BM;
-    const long long mrow0 = (long long)b * a.Lp + a.P + l0 - TAPS / 2;
-
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wco = wave / WPOS, wpos = wave % WPOS;
-
-    // ---- LDS-DMA source addressing: this lane fills slot (lane & 3) of row 16*j + (lane >> 2) ----
-    const int srow = lane >> 2, sslot = lane & 3;
-    const unsigned char* xg = reinterpret_cast<const unsigned char*>(a.x);
-    const unsigned char* wg = reinterpret_cast<const unsigned char*>(a.w);
-    const long long xplane = a.M * 64;
-    const long long wchunk = (long long)TAPS * a.CoutPad * 64;
-
-    auto stage = [&](int kc) {
-        const unsigned char* xb = xg + kc * xplane;
-        const unsigned char* wb = wg + kc * wchunk;
-#pragma unroll
-        for (int j0 = 0; j0 < NXI; j0 += 4) {
-            const int j = j0 + wave;
-            if (j < NXI) {
-                const int row = j * 16 + srow;
-                long long m = mrow0 + row;
-                m = m < 0 ? 0 : (m >= a.M ? a.M - 1 : m);
-                glds16(xb + m * 64 + ((sslot ^ ((row >> 2) & 3)) << 4), xs + j * 1024);
-            }
-        }
-#pragma unroll
-        for (int j0 = 0; j0 < NWI; j0 += 4) {
-            const int j = j0 + wave;
-            if (j < NWI) {
-                const int row = j * 16 + srow;              // = tap * BN + co_local
-                const int tap = row / BN, col = row % BN;
-                glds16(wb + (long long)(tap * a.CoutPad + cobase + col) * 64 + ((sslot ^ ((row >> 2) & 3)) << 4),
-                       ws + j * 1024);
-            }
-        }
-    };
-
-    f32x16 acc[TCO][TPOS];
-#pragma unroll
-    for (int i = 0; i < TCO; ++i)
-#pragma unroll
-        for (int j = 0; j < TPOS; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // fragment rows: weights at (tap*BN + wco*TCO*32 + i*32 + l31), activations at (wpos*TPOS*32 + j*32 + l31 + tap)
-    const unsigned char* wfrag = ws + (wco * TCO * 32 + l31) * 64;
-    const unsigned char* xfrag = xs + (wpos * TPOS * 32 + l31) * 64;
-    const int wsw = (l31 >> 2) & 3;              // tile offsets are multiples of 16 rows: swizzle depends on l31 only
-
-    for (int kc = 0; kc < a.nchunks; ++kc) {
-        stage(kc);
-        __syncthreads();                         // waits for this wave's LDS-DMA (vmcnt) + block barrier
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int xsw = ((l31 + tap) >> 2) & 3;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int p = 2 * s + h;
-                Frag af[TCO], bf[TPOS];
-#pragma unroll
-                for (int i = 0; i < TCO; ++i)
-                    af[i] = *reinterpret_cast<const Frag*>(wfrag + (tap * BN + i * 32) * 64 + ((p ^ wsw) << 4));
-#pragma unroll
-                for (int j = 0; j < TPOS; ++j)
-                    bf[j] = *reinterpret_cast<const Frag*>(xfrag + (j * 32 + tap) * 64 + ((p ^ xsw) << 4));
-#pragma unroll
-                for (int i = 0; i < TCO; ++i)
-#pragma unroll
-                    for (int j = 0; j < TPOS; ++j) Mma<T>::run(af[i], bf[j], acc[i][j]);
-            }
-        }
-        __syncthreads();                         // every wave is done reading before the next stage lands
-    }
-
-    conv_epilogue<TO, BN, BM, WPOS, TCO, TPOS>(a, acc, smem, b, t, cot, cobase, l0, tid, l31, h, wco, wpos);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Pipelined variant (co tile 128): the K loop runs in PHASES of one (channel chunk, tap) each.  The
-// unit of prefetch is one tap's weight tile W(kc, tap) (128 rows x 64 B = 8 KiB = 2 LDS-DMA instructions
-// per wave) held in a ring of K+1 slots; the activation tile X(kc) (BM + taps - 1 rows, shared by all
-// taps of the chunk) is double-buffered and issued just ahead of W(kc, 0).  Every wave issues the same
-// number of LDS-DMA instructions per unit, so "unit u has landed" is one counted s_waitcnt vmcnt(N)
-// (N = this wave's instructions issued AFTER unit u, a compile-time constant per tap) followed by one
-// raw s_barrier per phase; K-2 units stay in flight across barriers (never vmcnt(0) in steady state).
-// Fragments are register double-buffered ACROSS the barrier so no ds_read latency sits in front of an
-// MFMA group:
-//   phase g:  ds_read frags(g, k-step 1) | MFMAs(g, k-step 0) | wait unit g+1 -> s_barrier -> issue unit
-//             g+K (into the slot phase g-1 released) | ds_read frags(g+1, k-step 0) | MFMAs(g, k-step 1)
-template <int N> __device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-template <typename T, typename TO, int TAPS, int WCO, int WPOS, int TCO, int TPOS>
-__global__ __launch_bounds__(WCO * WPOS * 64, 2) void conv_mfma_kernel(const ConvArgs a)
-{
-    constexpr int BN = WCO * TCO * 32, BM = WPOS * TPOS * 32;
-    constexpr int NW = WCO * WPOS;               // waves per block: 4 (two blocks per CU) or 8 (one block per CU)
-    static_assert((NW == 4 || NW == 8) && BN % (16 * NW) == 0, "pipelined variant: 4 or 8 waves");
-    constexpr int K = TAPS >= 3 ? 4 : 2;         // unit g+K is issued during phase g
-    constexpr int RW = K + 1, RX = TAPS == 1 ? K + 1 : 2;
-    constexpr int XROWS = BM + TAPS - 1;
-    constexpr int XI = (XROWS + 16 * NW - 1) / (16 * NW);    // X LDS-DMA instructions per wave (uniform; tile padded)
-    constexpr int WI = BN / (16 * NW);                        // W LDS-DMA instructions per wave per unit
-    constexpr int XBYTES = XI * NW * 1024, WBYTES = BN * 64;
-    typedef typename Mma<T>::Frag Frag;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* xs = smem;                    // [RX][XBYTES]
-    unsigned char* ws = smem + RX * XBYTES;      // [RW][WBYTES]
-
-    const unsigned lid = xcd_remap(blockIdx.x, a.nblk);
-    const int cot = (int)(lid % (unsigned)a.ncot);
-    const unsigned r1 = lid / (unsigned)a.ncot;
-    const int t = (int)(r1 % (unsigned)a.tps);
-    const int b = (int)(r1 / (unsigned)a.tps);
-    const int cobase = cot * BN;
-    const int l0 = t * BM;
-    const long long mrow0 = (long long)b * a.Lp + a.P + l0 - TAPS / 2;
-
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wco = wave / WPOS, wpos = wave % WPOS;
-    const int srow = lane >> 2, sslot = lane & 3;
-
-    const unsigned char* xg = reinterpret_cast<const unsigned char*>(a.x);
-    const unsigned char* wg = reinterpret_cast<const unsigned char*>(a.w);
-    const long long xplane = a.M * 64;
-    const long long wchunk = (long long)TAPS * a.CoutPad * 64;
-    const int total = a.nchunks * TAPS;
-
-    // per-lane source offsets (bytes) inside a plane / a weight chunk, fixed for the whole kernel
-    unsigned xsrc[XI], wsrc[WI];
-#pragma unroll
-    for (int j = 0; j < XI; ++j) {
-        const int row = (j * NW + wave) * 16 + srow;
-        long long m = mrow0 + row;
-        m = m < 0 ? 0 : (m >= a.M ? a.M - 1 : m);
-        xsrc[j] = (unsigned)(m * 64 + ((sslot ^ ((row >> 2) & 3)) << 4));
-    }
-#pragma unroll
-    for (int j = 0; j < WI; ++j) {
-        const int row = (j * NW + wave) * 16 + srow;         // co_local
-        wsrc[j] = (unsigned)((cobase + row) * 64 + ((sslot ^ ((row >> 2) & 3)) << 4));
-    }
-
-    auto issue_unit = [&](int u) {               // u = kc * TAPS + tap, wave-uniform
-        const int kc = u / TAPS, tap = u - kc * TAPS;
-        if (tap == 0) {
-            const unsigned char* xb = xg + kc * xplane;
-            unsigned char* dst = xs + (kc % RX) * XBYTES + wave * 1024;
-#pragma unroll
-            for (int j = 0; j < XI; ++j) glds16(xb + xsrc[j], dst + j * (NW * 1024));
-        }
-        const unsigned char* wb = wg + kc * wchunk + (long long)tap * a.CoutPad * 64;
-        unsigned char* dst = ws + (u % RW) * WBYTES + wave * 1024;
-#pragma unroll
-        for (int j = 0; j < WI; ++j) glds16(wb + wsrc[j], dst + j * (NW * 1024));
-    };
-
-    f32x16 acc[TCO][TPOS];
-#pragma unroll
-    for (int i = 0; i < TCO; ++i)
-#pragma unroll
-        for (int j = 0; j < TPOS; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int wfrag = (wco * TCO * 32 + l31) * 64;
-    const int xfrag = (wpos * TPOS * 32 + l31) * 64;
-    const int wsw = (l31 >> 2) & 3;
-
-#define ADK_LOAD_FRAGS(AF_, BF_, WT_, XT_, XSW_, S_)                                                        \
-    {                                                                                                        \
-        const int p_ = 2 * (S_) + h;                                                                         \
-        _Pragma("unroll") for (int i = 0; i < TCO; ++i)                                                      \
-            AF_[i] = *reinterpret_cast<const Frag*>((WT_) + i * 2048 + ((p_ ^ wsw) << 4));                   \
-        _Pragma("unroll") for (int j = 0; j < TPOS; ++j)                                                     \
-            BF_[j] = *reinterpret_cast<const Frag*>((XT_) + j * 2048 + ((p_ ^ (XSW_)) << 4));                \
-    }
-#define ADK_MMA_ALL(AF_, BF_)                                                                                \
-    _Pragma("unroll") for (int i = 0; i < TCO; ++i)                                                          \
-        _Pragma("unroll") for (int j = 0; j < TPOS; ++j) Mma<T>::run(AF_[i], BF_[j], acc[i][j]);
-
-    Frag a0[TCO], b0[TPOS], a1[TCO], b1[TPOS];
-
-    // prologue: units 0..K-1 in flight, wait for unit 0, first fragments
-#pragma unroll
-    for (int u = 0; u < K; ++u)
-        if (u < total) issue_unit(u);
-    {
-        constexpr int n0 = []() { int n = 0; for (int u = 1; u < K; ++u) n += WI + (u % TAPS == 0 ? XI : 0); return n; }();
-        if (total >= K) wait_vmcnt<n0>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        ADK_LOAD_FRAGS(a0, b0, ws + wfrag, xs + xfrag, wsw, 0)
-    }
-
-// n_mid / n_last: LDS-DMA instructions this wave has issued after unit g+1 when phase g waits for it
-#define ADK_PHASE(TAP_)                                                                                      \
-    if constexpr (TAP_ < TAPS) {                                                                             \
-        constexpr int n_mid = []() { int n = 0; for (int u = 2; u < K; ++u) n += WI + ((TAP_ + u) % TAPS == 0 ? XI : 0); return n; }(); \
-        constexpr int n_last = []() { int n = 0; for (int u = 2; u < K; ++u) n += (TAP_ + u < TAPS) ? WI : 0; return n; }();          \
-        const int g_ = kc * TAPS + TAP_;                                                                     \
-        {                                                                                                    \
-            const unsigned char* wt_ = ws + (g_ % RW) * WBYTES + wfrag;                                      \
-            const unsigned char* xt_ = xs + (kc % RX) * XBYTES + xfrag + TAP_ * 64;                          \
-            ADK_LOAD_FRAGS(a1, b1, wt_, xt_, ((l31 + TAP_) >> 2) & 3, 1)                                     \
-        }                                                                                                    \
-        ADK_MMA_ALL(a0, b0)                                                                                  \
-        if (g_ + 1 < total) {                                                                                \
-            if (last) wait_vmcnt<n_last>(); else wait_vmcnt<n_mid>();                                        \
-            __builtin_amdgcn_s_barrier();                                                                    \
-            asm volatile("" ::: "memory");                                                                   \
-            if (g_ + K < total) issue_unit(g_ + K);                                                          \
-            constexpr int nt_ = (TAP_ + 1) % TAPS;                                                           \
-            const int nkc_ = kc + (TAP_ + 1 == TAPS ? 1 : 0);                                                \
-            const unsigned char* wt_ = ws + ((g_ + 1) % RW) * WBYTES + wfrag;                                \
-            const unsigned char* xt_ = xs + (nkc_ % RX) * XBYTES + xfrag + nt_ * 64;                         \
-            ADK_LOAD_FRAGS(a0, b0, wt_, xt_, ((l31 + nt_) >> 2) & 3, 0)                                      \
-        }                                                                                                    \
-        ADK_MMA_ALL(a1, b1)                                                                                  \
-    }
-
-    for (int kc = 0; kc < a.nchunks; ++kc) {
-        const bool last = kc == a.nchunks - 1;
-        ADK_PHASE(0) ADK_PHASE(1) ADK_PHASE(2) ADK_PHASE(3) ADK_PHASE(4) ADK_PHASE(5) ADK_PHASE(6)
-    }
-#undef ADK_PHASE
-#undef ADK_LOAD_FRAGS
-#undef ADK_MMA_ALL
-    __syncthreads();      // all fragment reads done before the epilogue reuses LDS for its reduction
-
-    conv_epilogue<TO, BN, BM, WPOS, TCO, TPOS>(a, acc, smem, b, t, cot, cobase, l0, tid, l31, h, wco, wpos);
-}
-
-// ------------------------------------------------------------------------------------------------
-template <typename T, typename TO, int TAPS, int WCO, int WPOS, int TCO, int TPOS>
-static int launch_variant(const adk_op& op, hipStream_t st)
-{
-    constexpr int BN = WCO * TCO * 32, BM = WPOS * TPOS * 32;
-    ConvArgs a;
-    conv_fill_args(op, BN, BM, a);
-    if constexpr (BN >= 128) {
-        constexpr int K = TAPS >= 3 ? 4 : 2;
-        constexpr int NW = WCO * WPOS;
-        constexpr int XI = (BM + TAPS - 1 + 16 * NW - 1) / (16 * NW);
-        const size_t lds = (size_t)(TAPS == 1 ? K + 1 : 2) * XI * NW * 1024 + (size_t)(K + 1) * BN * 64;
-        static bool attr_set = false;             // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<T, TO, TAPS, WCO, WPOS, TCO, TPOS>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return ADK_ELAUNCH;
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((conv_mfma_kernel<T, TO, TAPS, WCO, WPOS, TCO, TPOS>), dim3(a.nblk), dim3(NW * 64), lds, st, a);
-    } else {
-        const size_t lds = (size_t)((BM + TAPS - 1 + 15) / 16) * 1024 + (size_t)TAPS * BN * 64;
-        hipLaunchKernelGGL((conv_mfma_simple_kernel<T, TO, TAPS, WCO, WPOS, TCO, TPOS>), dim3(a.nblk), dim3(256), lds, st, a);
-    }
-    return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
-}
+#include "conv_mfma_kernels.h"
 
 void conv_fill_args(const adk_op& op, int BN, int BM, ConvArgs& a)
 {
@@ -434,6 +27,9 @@ void conv_fill_args(const adk_op& op, int BN, int BM, ConvArgs& a)
     a.ncot = op.CoutPad / BN;
     a.nblk = (unsigned)(op.B * a.tps * a.ncot);
     a.gstats = (op.flags & ADK_FLAG_GROUP_STATS) ? 1 : 0;
+    a.dil = op.i0 > 1 ? op.i0 : 1;
+    a.shift = (op.flags & ADK_FLAG_CAUSAL) ? (op.taps - 1) * a.dil : (op.taps / 2) * a.dil;
+    a.elu = (op.flags & ADK_FLAG_ELU) ? 1 : 0;
 }
 
 // tile-shape selection (host); adk_conv_cotile / adk_conv_postile / adk_partials_count report it.
@@ -467,23 +63,13 @@ int conv_partials_count(const adk_op& op)
     return ((op.L + t.bm - 1) / t.bm) * (op.CoutPad / t.bn);
 }
 
-template <typename T, typename TO, int TAPS>
-static int launch_tiles(const adk_op& op, hipStream_t st)
-{
-    const ConvTile t = conv_tile(op);
-    if (t.bn == 32) return launch_variant<T, TO, TAPS, 1, 4, 1, 1>(op, st);
-    if (t.bm == 256) return launch_variant<T, TO, TAPS, 2, 2, 2, 4>(op, st);
-    if (t.bm == 64) return launch_variant<T, TO, TAPS, 2, 2, 2, 1>(op, st);
-    return launch_variant<T, TO, TAPS, 2, 2, 2, 2>(op, st);
-}
-
 template <typename T, typename TO>
 static int launch_taps(const adk_op& op, hipStream_t st)
 {
-    if (op.taps == 1) return launch_tiles<T, TO, 1>(op, st);
-    if (op.taps == 5) return launch_tiles<T, TO, 5>(op, st);
-    if (op.taps == 3) return launch_tiles<T, TO, 3>(op, st);      // learned resamplers (blocks/blocks.py:214-255)
-    if (op.taps == 7) return launch_tiles<T, TO, 7>(op, st);      // kernel_size=7 models (train_uncond.py:97-106)
+    if (op.taps == 1) return launch_tiles<false, T, TO, 1>(op, st);
+    if (op.taps == 5) return launch_tiles<false, T, TO, 5>(op, st);
+    if (op.taps == 3) return launch_tiles<false, T, TO, 3>(op, st);      // learned resamplers (blocks/blocks.py:214-255)
+    if (op.taps == 7) return launch_tiles<false, T, TO, 7>(op, st);      // kernel_size=7 models (train_uncond.py:97-106)
     return ADK_EINVAL;
 }
 
@@ -491,6 +77,7 @@ int launch_conv(const adk_op& op, hipStream_t st)
 {
     const ConvTile ct = conv_tile(op);
     if (ct.ksplit) return launch_conv_ksplit(op, st);
+    if ((op.flags & (ADK_FLAG_CAUSAL | ADK_FLAG_ELU | ADK_FLAG_GROUP_STATS)) || op.i0 > 1) return launch_conv_ext(op, st);
     if (op.dtype == ADK_F32) return launch_taps<float, float>(op, st);
     if (op.flags & ADK_FLAG_OUT_F32) return launch_taps<bf16_t, float>(op, st);
     return launch_taps<bf16_t, bf16_t>(op, st);

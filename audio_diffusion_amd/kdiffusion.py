@@ -289,6 +289,7 @@ class AudioDenoiserModel(nn.Module):
                                    self_attn=self_attn_depths[i], dropout_rate=dropout_rate))
         self.u_net = UNet(d_blocks, list(reversed(u_blocks)))
         self.compute_dtype = None          # None: fp32 (bf16 under torch.autocast)
+        self.use_graph = True              # replay each call as one captured hipGraph (identical bits, fewer submissions)
         self._wcache = {}
         self._plans = {}
 
@@ -361,16 +362,58 @@ class AudioDenoiserModel(nn.Module):
             raise RuntimeError(f"this model was built with unet_cond_dim={self.unet_cond_dim}: forward() needs `unet_cond`")
         plan = self.plan_for(B, x.shape[2], self.resolve_dtype(), dev, cond_len=uc.shape[2] if uc is not None else 0,
                              log_sigma=bool(log_sigma), has_mapping_cond=mc is not None, scaled=scalings is not None)
+        sc = None
+        if scalings is not None:
+            sc = [s.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous() for s in scalings]
+        if self.use_graph:
+            return self._run_captured(plan, x, sig, uc, mc, sc)
         out = torch.empty_like(x)
         ptrs = dict(input=x.data_ptr(), t=sig.data_ptr(), output=out.data_ptr(), cond=uc.data_ptr() if uc is not None else 0,
                     mapcond=mc.data_ptr() if mc is not None else 0)
-        keep = []
-        if scalings is not None:
-            keep = [s.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous() for s in scalings]
-            ptrs.update(cskip=keep[0].data_ptr(), cout=keep[1].data_ptr(), cin=keep[2].data_ptr())
+        if sc is not None:
+            ptrs.update(cskip=sc[0].data_ptr(), cout=sc[1].data_ptr(), cin=sc[2].data_ptr())
         plan.bind_named(**ptrs)
         plan.run(torch.cuda.current_stream(dev).cuda_stream)
         return out
+
+    def _run_captured(self, plan, x, sig, uc, mc, sc):
+        """One hipGraph per plan: the ~300 launches of a call replay as one submission (a sampler calls the denoiser
+        1-2 times per step with fresh tensors, so inputs are copied into plan-owned static buffers first)."""
+        dev = x.device
+        st = getattr(plan, "static", None)
+        if st is None:
+            st = dict(input=torch.empty_like(x), t=torch.empty_like(sig), output=torch.empty_like(x))
+            if uc is not None:
+                st["cond"] = torch.empty_like(uc)
+            if mc is not None:
+                st["mapcond"] = torch.empty_like(mc)
+            if sc is not None:
+                st.update(cskip=torch.empty_like(sc[0]), cout=torch.empty_like(sc[1]), cin=torch.empty_like(sc[2]))
+            plan.bind_named(**{k: v.data_ptr() for k, v in st.items()})
+            plan.static, plan.graph = st, None
+        st["input"].copy_(x)
+        st["t"].copy_(sig)
+        if uc is not None:
+            st["cond"].copy_(uc)
+        if mc is not None:
+            st["mapcond"].copy_(mc)
+        if sc is not None:
+            for k, v in zip(("cskip", "cout", "cin"), sc):
+                st[k].copy_(v)
+        if plan.graph is None:
+            cur = torch.cuda.current_stream(dev)
+            side = torch.cuda.Stream(device=dev)            # warm-up outside capture (code-object loading)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                plan.run(side.cuda_stream)
+            cur.wait_stream(side)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                plan.run(torch.cuda.current_stream(dev).cuda_stream)
+            plan.graph = g
+        plan.graph.replay()
+        return st["output"].clone()
 
     def forward(self, input, sigma, mapping_cond=None, unet_cond=None, log_sigma=True):
         return self.run(input, sigma, mapping_cond, unet_cond, log_sigma)

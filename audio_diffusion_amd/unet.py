@@ -79,7 +79,7 @@ class _Plan:
         self.dtype = dtype
         self.adk_dtype = _lib.ADK_F32 if dtype == torch.float32 else _lib.ADK_BF16
         self.CB = 16 if dtype == torch.float32 else 32
-        self.P = model.kernel_size // 2
+        self.P = getattr(model, "halo_rows", None) or model.kernel_size // 2
         self.planner = _ArenaPlanner()
         self.peak = 0
         self._ops = []            # (AdkOp, {field: ('arena', off) | ('abs', ptr)})
@@ -152,7 +152,8 @@ class _Plan:
         self.meta.append({"kind": kind})
         return op
 
-    def conv(self, x, key, w, bias, Cout, out=None, residual=None, stats=False, out_f32=False, gstats=False):
+    def conv(self, x, key, w, bias, Cout, out=None, residual=None, stats=False, out_f32=False, gstats=False,
+             dilation=1, causal=False, elu=False):
         taps = w.shape[2]
         bn = self.lib.adk_conv_cotile(self.adk_dtype, Cout, x.L)
         cout_pad = _ceil_to(Cout, bn)
@@ -167,7 +168,12 @@ class _Plan:
         flags = _lib.FLAG_OUT_F32 if (out_f32 and self.dtype != torch.float32) else 0
         if stats and gstats:              # one partial list per 32-channel group (AdaGN consumers, kdiffusion.py)
             flags |= _lib.FLAG_GROUP_STATS
-        op = self._emit(_lib.OP_CONV, ptrs, flags=flags, L=x.L, Cin=cin_alloc, Cout=Cout, CoutPad=cout_pad, taps=taps)
+        if causal:                        # CausalConv1d / dilation / fused ELU: soundstream.py
+            flags |= _lib.FLAG_CAUSAL
+        if elu:
+            flags |= _lib.FLAG_ELU
+        op = self._emit(_lib.OP_CONV, ptrs, flags=flags, L=x.L, Cin=cin_alloc, Cout=Cout, CoutPad=cout_pad, taps=taps,
+                        i0=dilation if dilation > 1 else 0)
         self.meta[-1].update(taps=taps, L=x.L, cin=w.shape[1], cout=Cout, cotile=self.lib.adk_conv_cotile_used(ctypes.byref(op)),
                              postile=self.lib.adk_conv_postile(ctypes.byref(op)),
                              flops=2.0 * w.shape[1] * Cout * taps * x.L * self.B,

@@ -67,6 +67,10 @@ enum {
 #define ADK_FLAG_LOG 16u        /* FOURIER: embed log(sigma)/4 instead of sigma                    */
 #define ADK_FLAG_NO_EMBED 32u   /* PACK_INPUT: no timestep-embedding channels ([x | cond] only)    */
 #define ADK_FLAG_WT 128u         /* LINEAR: w is given transposed, [Cin][Cout] (wide layers: coalesced, read once) */
+#define ADK_FLAG_CAUSAL 256u     /* CONV: CausalConv1d (autoencoders/soundstream.py:11-17): tap k reads x[t - (taps-1-k)*dil],
+                                   i.e. left padding dil*(taps-1); needs halo P >= dil*(taps-1).  op.i0 = dilation
+                                   (1, and 3 / 9 for taps = 7) */
+#define ADK_FLAG_ELU 512u        /* CONV: nn.ELU() on the result (after bias and residual): soundstream.py:46,94-110 */
 #define ADK_FLAG_GROUP_STATS 64u /* CONV: partials_out holds one (sum,sumsq) list per 32-channel group,
                                    [B][ceil(Cout/32)][adk_partials_count / groups][2], for a following
                                    AdaGN / GroupNorm(C/32, C) (blocks/blocks.py:63, 93, 97)          */

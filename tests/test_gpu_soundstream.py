@@ -1,0 +1,85 @@
+"""SURVEY 8(f4), SoundStream-XL decoder on the GPU against the reference's goldens (tests/golden/sstream_*.npz) and,
+at the default architecture, against the CPU oracle; plus the dilated causal conv kernel through the C ABI.
+Tolerances: fp32 1e-4 (max error / max |ref|), bf16 L2 3e-2."""
+import ctypes
+import json
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_npz, sub_sd, rel_err
+from test_gpu_kdiff import to_cpl, from_cpl
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("name", ["sstream_tiny.npz", "sstream_s8.npz"])
+def test_decoder_vs_reference_golden(name):
+    from audio_diffusion_amd.soundstream import SoundStreamXLDecoder
+    z = load_npz(name)
+    m = SoundStreamXLDecoder(**json.loads(bytes(z["cfg"]).decode()))
+    m.load_state_dict(sub_sd(z, "sd/"), strict=True)
+    m = m.to(DEV).eval()
+    lat, ref = torch.from_numpy(z["z"]).to(DEV), torch.from_numpy(z["y"])
+    m.compute_dtype = torch.float32
+    y = m(lat)
+    assert y.shape == ref.shape and rel_err(y, ref) <= 1e-4
+    assert torch.equal(y, m(lat)), "reruns must be bit-identical"
+    assert torch.equal(m(lat[1:2].contiguous())[0], y[1]), "a sample's result must not depend on its batch"
+    m.compute_dtype = torch.bfloat16
+    yb = m(lat).cpu()
+    assert float((yb - ref).norm() / ref.norm()) <= 3e-2
+
+
+def test_default_architecture_vs_oracle():
+    """The reference's default decoder (8.9 M parameters, x1280 upsampling) on 6 latent frames."""
+    from audio_diffusion_amd.soundstream import SoundStreamXLDecoder
+    from oracle import soundstream_oracle as O
+    torch.manual_seed(4)
+    m = SoundStreamXLDecoder().eval()
+    lat = torch.randn(2, 128, 6)
+    want = O.decoder_forward(m.state_dict(), m.strides, lat)
+    m = m.to(DEV)
+    m.compute_dtype = torch.float32
+    got = m(lat.to(DEV))
+    assert got.shape == (2, 2, 6 * 1280) and rel_err(got, want) <= 1e-4
+    m.compute_dtype = torch.bfloat16
+    assert float((m(lat.to(DEV)).cpu() - want).norm() / want.norm()) <= 3e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,Co,L,dil", [(32, 32, 300, 1), (32, 32, 1000, 9), (64, 64, 70, 3), (64, 128, 700, 9),
+                                         (128, 128, 3000, 3), (256, 256, 40, 9), (128, 128, 200, 1)])
+def test_dilated_causal_conv_elu(dtype, C, Co, L, dil):
+    """adk_run_plan with ADK_FLAG_CAUSAL | ADK_FLAG_ELU and a residual, all tile shapes (simple, k-split, pipelined)."""
+    from audio_diffusion_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(C + L + dil)
+    B, P, cb = 2, 54, 16 if dtype == torch.float32 else 32
+    adt = _lib.ADK_F32 if dtype == torch.float32 else _lib.ADK_BF16
+    x = torch.randn(B, C, L, device=DEV)
+    w = torch.randn(Co, C, 7, device=DEV) * (C * 7) ** -0.5
+    bias, res = torch.randn(Co, device=DEV), torch.randn(B, Co, L, device=DEV)
+    bn = lib.adk_conv_cotile(adt, Co, L)
+    cop = (Co + bn - 1) // bn * bn
+    wp = torch.zeros(cop, C, 7, device=DEV)
+    wp[:Co] = w
+    wp = wp.view(cop, C // cb, cb, 7).permute(1, 3, 0, 2).contiguous().to(dtype)
+    bp = torch.zeros(cop, device=DEV)
+    bp[:Co] = bias
+    xs, rs = to_cpl(x, P, cb, dtype), to_cpl(res, P, cb, dtype)
+    out = torch.full_like(rs, 5.0)
+    op = _lib.AdkOp()
+    op.kind, op.dtype, op.flags = _lib.OP_CONV, adt, _lib.FLAG_CAUSAL | _lib.FLAG_ELU
+    op.B, op.L, op.P, op.Cin, op.Cout, op.CoutPad, op.taps, op.i0 = B, L, P, C, Co, cop, 7, dil
+    op.x, op.w, op.bias, op.residual, op.y = xs.data_ptr(), wp.data_ptr(), bp.data_ptr(), rs.data_ptr(), out.data_ptr()
+    rc = lib.adk_run_plan(ctypes.byref(op), 1, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, lib.adk_last_error()
+    xin, wq = from_cpl(xs, C, P), wp.float().permute(2, 0, 3, 1).reshape(cop, C, 7)[:Co]
+    want = F.elu(F.conv1d(F.pad(xin, [6 * dil, 0]), wq, bias, dilation=dil) + from_cpl(rs, Co, P))
+    assert rel_err(from_cpl(out, Co, P), want) <= (1e-4 if dtype == torch.float32 else 2e-2)
+    assert not out[:, :, :P].any() and not out[:, :, -P:].any(), "halo rows must be zero"
+    op.P = 6 * dil - 1                                   # too little left halo for the causal padding: rejected
+    assert lib.adk_validate_plan(ctypes.byref(op), 1) != 0

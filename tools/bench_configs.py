@@ -29,6 +29,8 @@ CONFIGS = {
     # Karras Denoiser, input = 16 PQMF bands x 2 channels of a 524288-sample clip
     "k-audio": (dict(c_in=32, feats_in=128, depths=[2, 2, 2, 3, 3, 3, 4, 4], channels=[256, 256, 512, 512, 512, 512, 512, 512],
                      self_attn_depths=[False] * 5 + [True] * 3, strides=[4, 4, 4, 2, 2, 2, 2]), 4, 524288, torch.bfloat16),
+    # autoencoders/soundstream.py default decoder: 16 clips of 52 latent frames -> 2 x 66560 samples
+    "soundstream-dec": (dict(), 16, 66560, torch.bfloat16),
 }
 
 
@@ -54,7 +56,14 @@ def main():
     for name in names:
         kw, B, T, dtype = CONFIGS[name]
         torch.manual_seed(0)
-        if name == "k-audio":
+        if name == "soundstream-dec":
+            from audio_diffusion_amd.soundstream import SoundStreamXLDecoder
+            m = SoundStreamXLDecoder(**kw).to(dev).eval()
+            x = torch.randn(B, 128, T // m.upsampling(), device=dev)
+            plan = m.plan_for(B, x.shape[2], dtype, dev)
+            out = torch.empty(B, 2, T, device=dev)
+            plan.bind_named(input=x.data_ptr(), output=out.data_ptr())
+        elif name == "k-audio":
             m = A.AudioDenoiserModel(**kw).to(dev).eval()
             x = torch.randn(B, 32, T // 16, device=dev)
             t = torch.full((B,), 0.5, device=dev)
@@ -81,6 +90,16 @@ def main():
                "algorithmic_tflops": (flops + attn) / (ms * 1e-3) / 1e12,
                "audio_s_per_s_at_100_steps": B * T / SR / (ms * 1e-3 * 100), "arena_GB": plan.peak / 1e9,
                "n_ops": plan.n_ops}
+        if name == "k-audio":          # whole Denoiser call as the samplers issue it (input copies + one hipGraph replay)
+            den = A.Denoiser(m, 0.25)
+            m.compute_dtype = dtype
+            rec["ms_per_denoiser_call_graph"] = timed(lambda: den(x, t), max(a.reps, 20))
+            m.use_graph = False
+            rec["ms_per_denoiser_call_eager_api"] = timed(lambda: den(x, t), max(a.reps, 20))
+            sig = A.get_sigmas_karras(50, 1e-2, 3.0, rho=9., device=dev)
+            m.use_graph = True
+            rec["heun_50_sigmas_ms"] = timed(lambda: A.sample_heun(den, x, sig), 2)
+            rec["note"] = "heun: 99 denoiser calls (2 per step, Euler last); 524288-sample clips at 12 kHz"
         print(json.dumps(rec), flush=True)
         if name == "4":                                    # the filterbank kernels alone, [16, 2, 2^17], 32 bands
             xx = torch.randn(16, 2, 131072, device=dev)

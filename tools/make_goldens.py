@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate golden vectors by IMPORTING the reference (this container only).
 
-Run:  python tools/make_goldens.py [--tier B T C R K F] [--ref /root/reference]
+Run:  python tools/make_goldens.py [--tier B T C R K S F] [--ref /root/reference]
 Writes small fixtures (inputs + expected outputs, never source text) to tests/golden/.
 
 The reference's hot path is Python; three of its imports are unavailable or have drifted in this
@@ -10,6 +10,7 @@ the DiffusionAttnUnet1D path except ``cached_conv``, whose published semantics a
   * scipy.signal.kaiser (removed in SciPy 1.13; imported but unused at diffusion/pqmf.py:4)
   * cached_conv.{Conv1d,get_padding,USE_BUFFER_CONV} (third party, not vendored; pqmf.py:10-11)
   * local_attention / x_transformers (imported by autoencoders/transformer_ae.py:3-4, unused here)
+  * vector_quantize_pytorch.ResidualVQ (imported at autoencoders/soundstream.py:5, referenced only by a commented-out class)
   * scipy.signal.firwin(nyq=...) keyword removed in SciPy 1.12 -> fs=2*nyq (pqmf.py:72)
 This file never travels as a dependency of the product; it is the committed recipe for the
 fixtures.
@@ -65,6 +66,9 @@ def install_shims():
     la.transformer = lat
     sys.modules["local_attention"] = la
     sys.modules["local_attention.transformer"] = lat
+    vq = types.ModuleType("vector_quantize_pytorch")       # imported at autoencoders/soundstream.py:5, used only by a
+    vq.ResidualVQ = object                                  # commented-out class; never executed on the decoder path
+    sys.modules["vector_quantize_pytorch"] = vq
     xt = types.ModuleType("x_transformers")
     xt.ContinuousTransformerWrapper = xt.Encoder = object
     sys.modules["x_transformers"] = xt
@@ -307,6 +311,22 @@ def tier_kdiff():
             cfg=np.bytes_(json.dumps(kw).encode()), **{"extra/" + k: v for k, v in extra.items()}, **sd_arrays(m.state_dict()))
 
 
+def tier_soundstream():
+    """SoundStreamXLDecoder (autoencoders/soundstream.py:143-165), SURVEY 8 f4: small widths, every stride parity."""
+    print("tier S: SoundStream-XL decoder (SURVEY 8 f4)")
+    from autoencoders.soundstream import SoundStreamXLDecoder
+    cases = {"sstream_tiny": (dict(out_channels=2, capacity=32, latent_dim=24, c_mults=[2, 2, 4], strides=[2, 5, 4]), 2, 13),
+             "sstream_s8": (dict(out_channels=1, capacity=32, latent_dim=8, c_mults=[1, 2], strides=[3, 8]), 3, 40)}
+    for i, (name, (kw, B, L)) in enumerate(cases.items()):
+        torch.manual_seed(70 + i)
+        m = SoundStreamXLDecoder(**kw).eval()
+        torch.manual_seed(170 + i)
+        z = torch.randn(B, kw["latent_dim"], L)
+        with torch.no_grad():
+            y = m(z)
+        npz(name + ".npz", seed=np.int64(70 + i), z=z, y=y, cfg=np.bytes_(json.dumps(kw).encode()), **sd_arrays(m.state_dict()))
+
+
 def tier_full(Model, sampling):
     print("tier F: full 221M-param uncond model (seeds 0/1), digests + 10-step output")
     torch.manual_seed(0)
@@ -350,7 +370,7 @@ def tier_full(Model, sampling):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--tier", nargs="+", default=["B", "T", "C", "R", "K", "F"])
+    ap.add_argument("--tier", nargs="+", default=["B", "T", "C", "R", "K", "S", "F"])
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     P, Model, sampling, blocks = import_reference(a.ref)
@@ -364,6 +384,8 @@ def main():
         tier_learned(Model, sampling)
     if "K" in a.tier:
         tier_kdiff()
+    if "S" in a.tier:
+        tier_soundstream()
     if "F" in a.tier:
         tier_full(Model, sampling)
 

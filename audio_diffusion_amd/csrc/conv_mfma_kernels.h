@@ -247,7 +247,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <bool EXT, typename T, typename TO, int TAPS, int WCO, int WPOS, int TCO, int TPOS, int DIL = 1>
-__global__ __launch_bounds__(WCO * WPOS * 64, 2) void conv_mfma_kernel(const ConvArgs a)
+__global__ __launch_bounds__(WCO * WPOS * 64, (WCO * WPOS == 8 ? 1 : 2)) void conv_mfma_kernel(const ConvArgs a)
 {
     constexpr int BN = WCO * TCO * 32, BM = WPOS * TPOS * 32;
     constexpr int NW = WCO * WPOS;               // waves per block: 4 (two blocks per CU) or 8 (one block per CU)

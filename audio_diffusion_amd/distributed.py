@@ -73,3 +73,20 @@ def sample_sharded(model, noise, steps, eta, sampler):
     rank, world = dist.get_rank(), dist.get_world_size()
     lo, hi = shard_bounds(noise.shape[0], rank, world)
     return all_gather_audio(sampler(model, noise[lo:hi], steps, eta))
+
+
+@torch.no_grad()
+def run_sharded(fn, batch, *per_sample):
+    """Generic form for the other per-sample entry points (``lambda x: sample_heun(denoiser, x, sigmas)``, a
+    SoundStream decoder, a conditioned sampler with ``per_sample`` = (cond,)): every rank passes the SAME global
+    tensors; rank r runs ``fn(batch[lo:hi], *[a[lo:hi] for a in per_sample])`` on its contiguous shard and the
+    results are all-gathered in rank order.  The output may have any trailing shape; a rank whose shard is empty
+    (more ranks than samples) skips ``fn`` and learns the trailing shape from rank 0."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lo, hi = shard_bounds(batch.shape[0], rank, world)
+    local = fn(batch[lo:hi], *[a[lo:hi] for a in per_sample]) if hi > lo else None
+    meta = [None if local is None else (tuple(local.shape[1:]), local.dtype)]
+    dist.broadcast_object_list(meta, src=0)              # rank 0 always owns at least one sample
+    if local is None:
+        local = torch.empty((0,) + meta[0][0], dtype=meta[0][1], device=batch.device)
+    return all_gather_audio(local)

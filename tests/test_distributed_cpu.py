@@ -30,6 +30,10 @@ def _worker(rank, world, port, total, q):
     g = torch.Generator().manual_seed(1)
     noise = torch.randn(total, 2, 64, generator=g)      # generated once from one seed on every rank
     out = D.sample_sharded(None, noise, 5, 0, sampler=_fake_sampler)
+    # generic form: output with another trailing shape, a per-sample side input, empty shards
+    side = torch.arange(total, dtype=torch.float32)
+    up = D.run_sharded(lambda x, s: x.repeat_interleave(3, dim=2)[:, :1] * s[:, None, None], noise, side)
+    assert torch.equal(up, noise.repeat_interleave(3, dim=2)[:, :1] * side[:, None, None])
     mx = D.max_over_ranks(float(rank + 1), world, torch.device("cpu"))
     D.barrier(world)
     if rank == 0:

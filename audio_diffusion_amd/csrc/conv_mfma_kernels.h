@@ -252,7 +252,10 @@ __global__ __launch_bounds__(WCO * WPOS * 64, (WCO * WPOS == 8 ? 1 : 2)) void co
     constexpr int BN = WCO * TCO * 32, BM = WPOS * TPOS * 32;
     constexpr int NW = WCO * WPOS;               // waves per block: 4 (two blocks per CU) or 8 (one block per CU)
     static_assert((NW == 4 || NW == 8) && BN % (16 * NW) == 0, "pipelined variant: 4 or 8 waves");
-    constexpr int K = TAPS >= 3 ? 4 : 2;         // unit g+K is issued during phase g
+#ifndef ADK_CONV_K      // prefetch depth in units; -DADK_CONV_K=2 / 3 builds measured within 1 % of 4 on every level
+#define ADK_CONV_K 4
+#endif
+    constexpr int K = TAPS >= 3 ? ADK_CONV_K : 2;         // unit g+K is issued during phase g
     constexpr int RW = K + 1, RX = TAPS == 1 ? K + 1 : 2;
     constexpr int XROWS = BM + (TAPS - 1) * DIL;
     constexpr int XI = (XROWS + 16 * NW - 1) / (16 * NW);    // X LDS-DMA instructions per wave (uniform; tile padded)
@@ -397,7 +400,7 @@ static int launch_variant(const adk_op& op, hipStream_t st)
     ConvArgs a;
     conv_fill_args(op, BN, BM, a);
     if constexpr (BN >= 128) {
-        constexpr int K = TAPS >= 3 ? 4 : 2;
+        constexpr int K = TAPS >= 3 ? ADK_CONV_K : 2;
         constexpr int NW = WCO * WPOS;
         constexpr int XI = (BM + (TAPS - 1) * DIL + 16 * NW - 1) / (16 * NW);
         const size_t lds = (size_t)(TAPS == 1 ? K + 1 : 2) * XI * NW * 1024 + (size_t)(K + 1) * BN * 64;

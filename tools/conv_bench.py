@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--taps", type=int, default=5)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--zeros", action="store_true", help="all-zero operands (same instruction stream, far less switching power)")
     a = ap.parse_args()
     lib = _lib.load()
     dev = torch.device("cuda:0")
@@ -32,6 +33,8 @@ def main():
     cp = (a.cout + bn - 1) // bn * bn
     w = (torch.randn(a.cin // cb, a.taps, cp, cb, device=dev) / (a.cin * a.taps) ** 0.5).to(dtype)
     bias = torch.randn(cp, device=dev)
+    if a.zeros:
+        x.zero_(); w.zero_()
     y = torch.empty((a.cout + cb - 1) // cb, a.B, a.L + 2 * P, cb, dtype=dtype, device=dev)
     op = _lib.AdkOp()
     op.kind, op.dtype, op.L, op.Cout, op.CoutPad, op.Cin, op.B = _lib.OP_CONV, adk, a.L, a.cout, cp, a.cin, a.B

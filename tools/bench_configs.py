@@ -29,6 +29,9 @@ CONFIGS = {
     # Karras Denoiser, input = 16 PQMF bands x 2 channels of a 524288-sample clip
     "k-audio": (dict(c_in=32, feats_in=128, depths=[2, 2, 2, 3, 3, 3, 4, 4], channels=[256, 256, 512, 512, 512, 512, 512, 512],
                      self_attn_depths=[False] * 5 + [True] * 3, strides=[4, 4, 4, 2, 2, 2, 2]), 4, 524288, torch.bfloat16),
+    # autoencoders/models.py:262-296 latent diffusion denoiser (SURVEY 8 f1's consumer): 32-channel latents of length 4096
+    # (a 5.2 M-sample clip through the x1280 SoundStream encoder), conditioned on 32 x 256 second-stage latents
+    "latent-f1": (dict(io_channels=32, cond_dim=32, n_attn_layers=0, c_mults=[512] * 10, depth=10), 16, 4096, torch.bfloat16),
     # autoencoders/soundstream.py default decoder: 16 clips of 52 latent frames -> 2 x 66560 samples
     "soundstream-dec": (dict(), 16, 66560, torch.bfloat16),
 }
@@ -75,11 +78,12 @@ def main():
         else:
             m = A.DiffusionAttnUnet1D(**kw).to(dev).eval()
             m.compute_dtype = dtype
-            x = torch.randn(B, 2, T, device=dev)
+            x = torch.randn(B, kw.get("io_channels", 2), T, device=dev)
             t = torch.full((B,), 0.5, device=dev)
-            plan = m.plan_for(B, T, dtype, dev)
+            cond = torch.randn(B, kw["cond_dim"], T // 16, device=dev) if kw.get("cond_dim") else None
+            plan = m.plan_for(B, T, dtype, dev, cond_len=cond.shape[2] if cond is not None else 0)
             out = torch.empty_like(x)
-            plan.bind(x.data_ptr(), t.data_ptr(), out.data_ptr())
+            plan.bind(x.data_ptr(), t.data_ptr(), out.data_ptr(), cond.data_ptr() if cond is not None else 0)
         st = torch.cuda.current_stream(dev)
         ms = timed(lambda: plan.run(st.cuda_stream), a.reps)
         flops = sum(mt.get("flops", 0.0) for mt in plan.meta)

@@ -117,14 +117,16 @@ def pmc_traffic(key, tile):
     if not m or key != "bf16":
         return None
     tpos = int(m.group(2)) // 64
-    mangled = f"_Z16conv_mfma_kernelIDF16bDF16bLi5ELi2ELi2ELi2ELi{tpos}EEv8ConvArgs"
+    # conv_mfma_kernel<EXT=false, bf16, bf16, TAPS=5, WCO=2, WPOS=2, TCO=2, TPOS, DIL=1> (older summaries: no EXT / DIL)
+    pat = re.compile(rf"_Z16conv_mfma_kernelI(Lb0E)?DF16bDF16bLi5ELi2ELi2ELi2ELi{tpos}E(Li1E)?Ev8ConvArgs$")
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.json")), reverse=True):
         try:
-            e = json.load(open(f)).get(mangled)
+            summary = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if e and "hbm_bytes_per_launch" in e:
-            return e["hbm_bytes_per_launch"]
+        for name, e in summary.items():
+            if pat.match(name) and "hbm_bytes_per_launch" in e:
+                return e["hbm_bytes_per_launch"]
     return None
 
 

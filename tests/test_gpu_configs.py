@@ -84,6 +84,23 @@ def test_config3b_vs_oracle_and_properties():
     assert torch.equal(y16, m(x.to(DEV), t.to(DEV)))
 
 
+def test_config3c_learned_strides_vs_oracle():
+    """Config 3c: 3b with the strides of k_audio_uncond_long_1.json through Downsample1d_2 / Upsample1d_2."""
+    kw = dict(io_channels=2, pqmf_bands=16, depth=8, c_mults=[256, 256, 512, 512, 512, 512, 512, 512], n_attn_layers=1,
+              learned_resample=True, strides=[1, 4, 4, 4, 2, 2, 2, 2])
+    m, ref = make(**kw)
+    torch.manual_seed(9)
+    x = torch.randn(2, 2, 262144)
+    t = torch.tensor([0.3, 0.8])
+    want = ref(x[:1], t[:1])                              # one sample on the CPU
+    m.compute_dtype = torch.float32
+    assert rel_err(m(x.to(DEV), t.to(DEV))[:1], want) <= 1e-4
+    m.compute_dtype = torch.bfloat16
+    y16 = m(x.to(DEV), t.to(DEV))
+    assert float((y16[:1].cpu() - want).norm() / want.norm()) <= 3e-2
+    assert torch.equal(y16, m(x.to(DEV), t.to(DEV)))
+
+
 def test_config4_pqmf32_vs_oracle_and_roundtrip():
     """Config 4: 2ch x 2^17 split into 32 bands, U-Net, synthesis; plus the filterbank's own round trip."""
     kw = dict(io_channels=2, pqmf_bands=32, depth=10, c_mults=[256, 256] + [512] * 8, n_attn_layers=2)

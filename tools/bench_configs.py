@@ -23,6 +23,9 @@ CONFIGS = {
     "3a": (dict(), 4, 262144, torch.bfloat16),
     "3b": (dict(io_channels=2, pqmf_bands=16, depth=8, c_mults=[256, 256, 512, 512, 512, 512, 512, 512],
                 n_attn_layers=1), 4, 262144, torch.bfloat16),
+    # 3c: 3b with the JSON's own strides through the learned resamplers (needs f2)
+    "3c": (dict(io_channels=2, pqmf_bands=16, depth=8, c_mults=[256, 256, 512, 512, 512, 512, 512, 512], n_attn_layers=1,
+                learned_resample=True, strides=[1, 4, 4, 4, 2, 2, 2, 2]), 4, 262144, torch.bfloat16),
     "4": (dict(io_channels=2, pqmf_bands=32, depth=10, c_mults=[256, 256] + [512] * 8, n_attn_layers=2),
           16, 131072, torch.bfloat16),
     # model_configs/k_audio_uncond_long_1.json (the k-diffusion consumer of config 3b): AudioDenoiserModel behind the

@@ -142,6 +142,20 @@ def fold_down_weight(w, factor):
     return out.reshape(co, f * c, 3)
 
 
+def fold_down_causal_weight(w, factor):
+    """CausalConv1d(k = 2f, stride f) (left padding 2f-1; autoencoders/soundstream.py:78-79) == CAUSAL 3-tap stride-1 conv over
+    the phase-folded input x'[p*C + c][m] = x[c][m*f + p]:  y[j] = sum_k w[k] x[(j-2) f + k + 1], so with q = k + 1
+    rows j-2 / j-1 / j carry phases q (1..f-1) / q - f (0..f-1) / 0.   w [Co, C, 2f] -> [Co, f*C, 3]."""
+    co, c, k = w.shape
+    f = factor
+    assert k == 2 * f
+    out = w.new_zeros(co, f, c, 3)
+    for kk in range(k):
+        q = kk + 1
+        out[:, q % f, :, q // f] = w[:, :, kk]
+    return out.reshape(co, f * c, 3)
+
+
 def fold_up_weight(wt, bias, factor, pad=None):
     """ConvTranspose1d(k = 2f, stride f, padding pad = f//2 + f%2, output_padding f%2) == 3-tap stride-1 conv
     producing f phases per input position, y[co][j*f + s] = z[s*Co + co][j]:  with r = (s + pad) mod f,

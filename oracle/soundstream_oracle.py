@@ -45,3 +45,21 @@ def decoder_forward(sd, strides, x):
     for i, s in enumerate(reversed(strides)):
         x = F.elu(decoder_block(sd, f"layers.{2 + 2 * i}.", x, s))
     return causal_conv(sd, f"layers.{2 + 2 * n}.", x)
+
+
+def encoder_block(sd, p, x, stride):
+    """autoencoders/soundstream.py:55-83: six residual units (each followed by ELU), then the strided causal conv."""
+    for k, d in zip(range(0, 11, 2), (1, 3, 9, 1, 3, 9)):
+        x = F.elu(residual_unit(sd, f"{p}layers.{k}.", x, d))
+    w = sd[p + "layers.12.weight"]
+    return F.conv1d(F.pad(x, [w.shape[2] - 1, 0]), w, sd[p + "layers.12.bias"], stride=stride)
+
+
+@torch.no_grad()
+def encoder_forward(sd, strides, x):
+    """SoundStreamXLEncoder.forward (autoencoders/soundstream.py:118-140)."""
+    sd = {k: v.detach().to(torch.float32).cpu() for k, v in sd.items()}
+    x = F.elu(causal_conv(sd, "layers.0.", x))
+    for i, s in enumerate(strides):
+        x = F.elu(encoder_block(sd, f"layers.{2 + 2 * i}.", x, s))
+    return causal_conv(sd, f"layers.{2 + 2 * len(strides)}.", x)

@@ -33,6 +33,40 @@ def test_decoder_vs_reference_golden(name):
     assert float((yb - ref).norm() / ref.norm()) <= 3e-2
 
 
+@pytest.mark.parametrize("name", ["sstream_enc_tiny.npz", "sstream_enc_s8.npz"])
+def test_encoder_vs_reference_golden(name):
+    from audio_diffusion_amd.soundstream import SoundStreamXLEncoder
+    z = load_npz(name)
+    m = SoundStreamXLEncoder(**json.loads(bytes(z["cfg"]).decode()))
+    m.load_state_dict(sub_sd(z, "sd/"), strict=True)
+    m = m.to(DEV).eval()
+    x, ref = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["y"])
+    m.compute_dtype = torch.float32
+    y = m(x)
+    assert y.shape == ref.shape and rel_err(y, ref) <= 1e-4
+    assert torch.equal(y, m(x)) and torch.equal(m(x[1:2].contiguous())[0], y[1])
+    m.compute_dtype = torch.bfloat16
+    assert float((m(x).cpu() - ref).norm() / ref.norm()) <= 3e-2
+    with pytest.raises(NotImplementedError):
+        m(x[..., :-1])                                   # length not a multiple of the total stride
+
+
+def test_default_autoencoder_roundtrip_shapes_vs_oracle():
+    """Default encoder (x1280 down) then default decoder on 3 latent frames, each half against the CPU oracle."""
+    from audio_diffusion_amd.soundstream import SoundStreamXLDecoder, SoundStreamXLEncoder
+    from oracle import soundstream_oracle as O
+    torch.manual_seed(5)
+    enc, dec = SoundStreamXLEncoder().eval(), SoundStreamXLDecoder().eval()
+    x = torch.randn(1, 2, 3 * 1280)
+    want_z = O.encoder_forward(enc.state_dict(), enc.strides, x)
+    want_y = O.decoder_forward(dec.state_dict(), dec.strides, want_z)
+    enc, dec = enc.to(DEV), dec.to(DEV)
+    enc.compute_dtype = dec.compute_dtype = torch.float32
+    zz = enc(x.to(DEV))
+    assert zz.shape == (1, 128, 3) and rel_err(zz, want_z) <= 1e-4
+    assert rel_err(dec(zz), want_y) <= 1e-4
+
+
 def test_default_architecture_vs_oracle():
     """The reference's default decoder (8.9 M parameters, x1280 upsampling) on 6 latent frames."""
     from audio_diffusion_amd.soundstream import SoundStreamXLDecoder

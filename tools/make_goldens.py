@@ -325,6 +325,17 @@ def tier_soundstream():
         with torch.no_grad():
             y = m(z)
         npz(name + ".npz", seed=np.int64(70 + i), z=z, y=y, cfg=np.bytes_(json.dumps(kw).encode()), **sd_arrays(m.state_dict()))
+    from autoencoders.soundstream import SoundStreamXLEncoder
+    ecases = {"sstream_enc_tiny": (dict(in_channels=2, capacity=32, latent_dim=24, c_mults=[2, 2, 4], strides=[2, 5, 4]), 2, 40 * 13),
+              "sstream_enc_s8": (dict(in_channels=1, capacity=32, latent_dim=8, c_mults=[1, 2], strides=[3, 8]), 3, 24 * 20)}
+    for i, (name, (kw, B, T)) in enumerate(ecases.items()):
+        torch.manual_seed(80 + i)
+        m = SoundStreamXLEncoder(**kw).eval()
+        torch.manual_seed(180 + i)
+        x = torch.randn(B, kw["in_channels"], T)
+        with torch.no_grad():
+            y = m(x)
+        npz(name + ".npz", seed=np.int64(80 + i), x=x, y=y, cfg=np.bytes_(json.dumps(kw).encode()), **sd_arrays(m.state_dict()))
 
 
 def tier_full(Model, sampling):

@@ -206,7 +206,7 @@ def main():
                        "batch_per_gpu": a.batch, "global_batch": a.batch * world, "ddim_steps": a.ddim_steps,
                        "parallelism": f"batch-parallel x{world}" + (" + RCCL all-gather of output" if world > 1 else "")},
             "ms_per_denoiser_call": ms / a.ddim_steps,
-            "model_tflops": 6.899e11 * a.batch * a.ddim_steps / (ms * 1e-3) / 1e12,
+            "model_tflops": 6.899e11 * a.batch * world * a.ddim_steps / (ms * 1e-3) / 1e12,        # whole job
         }
         if not a.no_roofline:
             rec["roofline"] = conv_roofline(model, a.batch, dtype, dev)

@@ -35,8 +35,10 @@ extern "C" {
 
 /* op kinds for adk_op / adk_run_plan */
 enum {
-    ADK_OP_CONV = 1,        /* nn.Conv1d k in {1,5}: blocks/blocks.py:70,73 (ResConvBlock), :68 (skip),
-                               :109-110 (qkv_proj/out_proj)                                          */
+    ADK_OP_CONV = 1,        /* nn.Conv1d k in {1,3,5,7}: blocks/blocks.py:70,73 (ResConvBlock), :68 (skip),
+                               :109-110 (qkv_proj/out_proj), :95,99 (ResModConvBlock), the folded learned
+                               resamplers (:214-255) and, with ADK_FLAG_CAUSAL / ELU / i0 = dilation, the
+                               SoundStream convolutions (autoencoders/soundstream.py:11-115)           */
     ADK_OP_GN_APPLY = 2,    /* nn.GroupNorm(1,C) [+ nn.GELU] [+ residual add]: blocks/blocks.py:71-75,
                                :14-15 (ResidualBlock add), :107,115 (attention norm)                 */
     ADK_OP_GN_STATS = 3,    /* per-sample (sum, sumsq) partials of a CPL tensor (GroupNorm statistics) */
@@ -116,7 +118,9 @@ int adk_conv_cotile(int dtype, int Cout, int L);
 
 /* ---- single-op entry points (thin wrappers that fill an adk_op and call adk_run_plan) ---- */
 
-/* Replaces nn.Conv1d(Cin, Cout, taps, padding=taps//2) (blocks/blocks.py:70,73; 1x1: :68,:109,:110).
+/* Replaces nn.Conv1d(Cin, Cout, taps, padding=taps//2) (blocks/blocks.py:70,73; 1x1: :68,:109,:110), taps in {1,3,5,7}.
+ * flags: ADK_FLAG_OUT_F32, ADK_FLAG_GROUP_STATS, ADK_FLAG_ELU (taps 1,3,7); causal / dilated taps go through adk_run_plan
+ * (adk_op.i0 = dilation).
  *   x   CPL [B,Cin,L] halo P (P >= taps/2); w packed [Cin/CB][taps][CoutPad][CB] (dtype);
  *   bias f32 [CoutPad] or NULL; residual CPL [B,Cout,L] or NULL (added to the result);
  *   y CPL [B,Cout,L]; partials_out f32 [B][adk_partials_count][2] or NULL (stats of y). */

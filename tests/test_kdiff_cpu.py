@@ -47,6 +47,9 @@ def test_ctor_parity_and_plan(name, dtype):
         assert sd[k].shape == ref_sd[k].shape, k
         if k.startswith("proj_out."):
             assert not sd[k].any()    # zero init (decoders/diffusion_decoder.py:281-282); the fixture re-draws it
+        elif k.startswith("mapping.") and k.endswith(".weight"):
+            # nn.init.orthogonal_ (blocks.py:296-297) goes through LAPACK QR: same draws, last bits depend on the CPU
+            assert torch.allclose(sd[k], ref_sd[k], rtol=0, atol=1e-5), k
         else:
             assert torch.equal(sd[k], ref_sd[k]), k
     m.load_state_dict(ref_sd, strict=True)

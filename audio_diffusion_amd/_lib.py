@@ -10,7 +10,24 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ADK_LIB") or os.path.join(_HERE, "libadk.so")     # ADK_LIB: A/B runs against another build
 
-ADK_F32, ADK_BF16 = 0, 1
+ADK_F32, ADK_BF16, ADK_F16 = 0, 1, 2
+
+
+def adk_dtype(dtype):
+    """torch dtype -> ADK_* code.  float16 is the dtype of the reference's own autocast region
+    (diffusion/sampling.py:30); bf16 and f16 share layout, kernels and MFMA rate."""
+    import torch
+    table = {torch.float32: ADK_F32, torch.bfloat16: ADK_BF16, torch.float16: ADK_F16}
+    if dtype not in table:
+        raise ValueError(f"compute dtype {dtype} is not supported (float32, bfloat16, float16)")
+    return table[dtype]
+
+
+def autocast_dtype():
+    """Reduced dtype to use when the caller wrapped the call in torch.autocast: float16 if that is what the
+    autocast region asks for, else bfloat16."""
+    import torch
+    return torch.float16 if torch.get_autocast_dtype("cuda") == torch.float16 else torch.bfloat16
 
 OP_CONV, OP_GN_APPLY, OP_GN_STATS, OP_FIR_DOWN, OP_FIR_UP, OP_ATTN = 1, 2, 3, 4, 5, 6
 OP_PACK_INPUT, OP_UNPACK_OUTPUT, OP_PQMF_ANALYSIS, OP_PQMF_SYNTHESIS = 7, 8, 9, 10

@@ -41,7 +41,7 @@ static inline int cb_of(int dtype) { return dtype == ADK_F32 ? 16 : 32; }
 
 static int check_geo(const adk_op& o, const char* what)
 {
-    REQUIRE(o.dtype == ADK_F32 || o.dtype == ADK_BF16, "%s: dtype %d unsupported", what, o.dtype);
+    REQUIRE(o.dtype == ADK_F32 || o.dtype == ADK_BF16 || o.dtype == ADK_F16, "%s: dtype %d unsupported", what, o.dtype);
     REQUIRE(o.B >= 1 && o.L >= 1 && o.P >= 0, "%s: bad geometry B=%d L=%d P=%d", what, o.B, o.L, o.P);
     REQUIRE((long long)o.B * (o.L + 2 * o.P) < (1LL << 25), "%s: B*(L+2P)=%lld rows exceed the 2^25 per-plane limit",
             what, (long long)o.B * (o.L + 2 * o.P));

@@ -5,7 +5,12 @@
 #include "../../include/adk.h"
 
 typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -16,6 +21,10 @@ template <> struct ElemTraits<float> {
     static constexpr int NV = 4;    // elements per 16-byte piece
 };
 template <> struct ElemTraits<bf16_t> {
+    static constexpr int CB = 32;
+    static constexpr int NV = 8;
+};
+template <> struct ElemTraits<f16_t> {      // IEEE half: the dtype of the reference's own autocast region (sampling.py:30)
     static constexpr int CB = 32;
     static constexpr int NV = 8;
 };
@@ -46,6 +55,35 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     union { bf16_t h[2]; uint32_t u; } cv;
     cv.h[0] = (bf16_t)lo; cv.h[1] = (bf16_t)hi;
     return cv.u;
+}
+// two 16-bit elements of one 32-bit word <-> two floats (element 0 in the low half)
+__device__ __forceinline__ f32x2 unpack2(uint32_t w, bf16_t) {
+    f32x2 v;
+    v.x = __uint_as_float(w << 16); v.y = __uint_as_float(w & 0xffff0000u);
+    return v;
+}
+__device__ __forceinline__ f32x2 unpack2(uint32_t w, f16_t) {
+    union { uint32_t u; f16x2 h; } cv;
+    cv.u = w;
+    return __builtin_convertvector(cv.h, f32x2);
+}
+__device__ __forceinline__ uint32_t pack2(float lo, float hi, bf16_t) { return pack_bf16x2(lo, hi); }
+__device__ __forceinline__ uint32_t pack2(float lo, float hi, f16_t) {
+    union { f16_t h[2]; uint32_t u; } cv;       // plain casts: round to nearest even (not v_cvt_pkrtz)
+    cv.h[0] = (f16_t)lo; cv.h[1] = (f16_t)hi;
+    return cv.u;
+}
+__device__ __forceinline__ void piece_to_float(const uint4& p, float (&f)[8], f16_t) {
+    const uint32_t w[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 v = unpack2(w[i], f16_t());
+        f[2 * i] = v.x; f[2 * i + 1] = v.y;
+    }
+}
+__device__ __forceinline__ uint4 float_to_piece(const float (&f)[8], f16_t) {
+    return make_uint4(pack2(f[0], f[1], f16_t()), pack2(f[2], f[3], f16_t()), pack2(f[4], f[5], f16_t()),
+                      pack2(f[6], f[7], f16_t()));
 }
 __device__ __forceinline__ uint4 float_to_piece(const float (&f)[4], float) {
     return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
@@ -91,25 +129,27 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-// GELU for the bf16 path: erf through Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, far below bf16
-// rounding), 15 VALU instructions (2 transcendental) instead of ~35 for erff: with exact erff the GroupNorm
-// pass is VALU-bound at ~5.1 TB/s, not HBM-bound.  gelu(v) = v - v*E/2 (v >= 0), v*E/2 (v < 0),
-// E = erfc(|v|/sqrt 2) = poly(t) exp(-z^2), t = 1/(1 + p z).
+// GELU for the bf16 path.  gelu(v) = max(v, 0) - |v| E / 2 with E = erfc(|v| / sqrt 2) = exp2(-u Q(u)),
+// u = min(|v|, 6.08) and Q a degree-5 polynomial (weighted minimax fit of -log2(erfc(z)) / z on (0, 4.3], folded
+// to u = z sqrt 2): |abs error| <= 2e-7 for |v| <= 12 (6e-7 at |v| = 1000), far below bf16 rounding.
+// 12 VALU instructions, ONE of them transcendental (quarter rate), against ~35 for erff and 15 (two
+// transcendental) for the Abramowitz-Stegun form used before: with either of those the GroupNorm pass was
+// VALU-bound (5.1 TB/s), not HBM-bound.
 __device__ __forceinline__ float gelu_fast(float v) {
-    const float z = fabsf(v) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
-    float p = 0.5f * 1.061405429f;
-    p = __builtin_fmaf(p, t, 0.5f * -1.453152027f);
-    p = __builtin_fmaf(p, t, 0.5f * 1.421413741f);
-    p = __builtin_fmaf(p, t, 0.5f * -0.284496736f);
-    p = __builtin_fmaf(p, t, 0.5f * 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
-    const float r = v * (p * t * e);
-    return v >= 0.f ? v - r : r;
+    const float u = fminf(fabsf(v), 6.08f);
+    float q = -3.224038610e-05f;
+    q = __builtin_fmaf(q, u, 7.605187619e-04f);
+    q = __builtin_fmaf(q, u, -8.046323462e-03f);
+    q = __builtin_fmaf(q, u, 5.334470532e-02f);
+    q = __builtin_fmaf(q, u, 4.588402605e-01f);
+    q = __builtin_fmaf(q, u, 1.151166223e+00f);
+    const float e = __builtin_amdgcn_exp2f(-(u * q));
+    return fmaxf(v, 0.f) - fabsf((0.5f * v) * e);
 }
 template <typename T> __device__ __forceinline__ float gelu_for(float v);
 template <> __device__ __forceinline__ float gelu_for<float>(float v) { return gelu_erf(v); }
 template <> __device__ __forceinline__ float gelu_for<bf16_t>(float v) { return gelu_fast(v); }
+template <> __device__ __forceinline__ float gelu_for<f16_t>(float v) { return gelu_fast(v); }
 
 // XCD-aware bijective remap of a 1-D block id: consecutive logical ids share an XCD (8 XCDs).
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {

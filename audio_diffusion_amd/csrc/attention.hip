@@ -31,8 +31,8 @@ template <typename T, int ATT_D>
 __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a)
 {
     constexpr int CB = ElemTraits<T>::CB, NV = ElemTraits<T>::NV;
-    constexpr int PPH = ATT_D / CB;                 // planes per head (1 bf16, 2 f32)
-    constexpr int PPR = ATT_D / NV;                 // 16-byte pieces per head row (4 bf16, 8 f32)
+    constexpr int PPH = ATT_D / CB;                 // planes per head (1 bf16 / f16, 2 f32)
+    constexpr int PPR = ATT_D / NV;                 // 16-byte pieces per head row (4 bf16 / f16, 8 f32)
     __shared__ __attribute__((aligned(16))) float Ks[ATT_TK][ATT_D];
     __shared__ __attribute__((aligned(16))) float Vs[ATT_TK][ATT_D];
 
@@ -152,9 +152,24 @@ struct AttnMfmaArgs {
 
 constexpr int ATT_VBUF = 2048;              // one 32-key V tile, linear [key][32] bf16
 
-template <int TQ, int DP>                     // DP = 64-byte planes per head (head dim 32 * DP)
+template <typename T> struct AttMma;           // 16-bit element type -> fragment type + MFMA (same shapes, same rate)
+template <> struct AttMma<bf16_t> {
+    typedef bf16x8 Frag;
+    static __device__ __forceinline__ f32x16 run(const Frag& a, const Frag& b, const f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct AttMma<f16_t> {
+    typedef f16x8 Frag;
+    static __device__ __forceinline__ f32x16 run(const Frag& a, const Frag& b, const f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <typename T, int TQ, int DP>         // DP = 64-byte planes per head (head dim 32 * DP)
 __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnMfmaArgs a)
 {
+    typedef typename AttMma<T>::Frag Frag;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -170,7 +185,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnMfmaArgs a)
     unsigned char* vlds = smem + wave * (2 * DP * ATT_VBUF);     // wave-private double buffer
 
     // Q fragments (B operand of S^T = K Q^T): lane (q = l31, h) holds Q[q][32 p + 16 ks + 8 h .. +7]
-    bf16x8 qf[TQ][DP][2];
+    Frag qf[TQ][DP][2];
 #pragma unroll
     for (int u = 0; u < TQ; ++u) {
         int q = (qt * TQ + u) * 32 + l31;
@@ -179,7 +194,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnMfmaArgs a)
         for (int p = 0; p < DP; ++p)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                qf[u][p][ks] = *reinterpret_cast<const bf16x8*>(qg + p * pstride + (long long)q * 64 + (2 * ks + h) * 16);
+                qf[u][p][ks] = *reinterpret_cast<const Frag*>(qg + p * pstride + (long long)q * 64 + (2 * ks + h) * 16);
     }
 
     // One K/V tile = 32 keys.  K goes straight to registers in A-fragment layout (lane (key = l31, h) holds
@@ -225,7 +240,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnMfmaArgs a)
     KvTile cur = fetch_tile(0);
     for (int kt = 0; kt < nt; ++kt) {
         unsigned char* vb = vlds + (kt & 1) * (DP * ATT_VBUF);
-        union { uint4 q; bf16x8 f; } kf[DP][2];
+        union { uint4 q; Frag f; } kf[DP][2];
 #pragma unroll
         for (int p = 0; p < DP; ++p) {
             *reinterpret_cast<uint4*>(vb + p * ATT_VBUF + lane * 16) = cur.v[p][0];
@@ -234,12 +249,12 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnMfmaArgs a)
         }
         if (kt + 1 < nt) cur = fetch_tile(kt + 1);
 
-        bf16x8 vf[DP][2];
+        Frag vf[DP][2];
 #pragma unroll
         for (int p = 0; p < DP; ++p)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                union { s16x4 v[2]; bf16x8 f; } cv;
+                union { s16x4 v[2]; Frag f; } cv;
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
                     cv.v[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -255,8 +270,8 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnMfmaArgs a)
             for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
             for (int p = 0; p < DP; ++p) {
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[p][0].f, qf[u][p][0], st, 0, 0, 0);
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[p][1].f, qf[u][p][1], st, 0, 0, 0);
+                st = AttMma<T>::run(kf[p][0].f, qf[u][p][0], st);
+                st = AttMma<T>::run(kf[p][1].f, qf[u][p][1], st);
             }
             // st[r] = <k_key, q_query>, key = 32 kt + (r & 3) + 8 (r >> 2) + 4 h, query = l31
             if (ragged) {
@@ -278,12 +293,12 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnMfmaArgs a)
                 psum += st[r];
             }
             lrun[u] = lrun[u] * alpha + psum;
-            bf16x8 pf[2];
+            Frag pf[2];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                union { uint32_t w[4]; bf16x8 f; } pk;
+                union { uint32_t w[4]; Frag f; } pk;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pk.w[e] = pack_bf16x2(st[8 * s + 2 * e], st[8 * s + 2 * e + 1]);
+                for (int e = 0; e < 4; ++e) pk.w[e] = pack2(st[8 * s + 2 * e], st[8 * s + 2 * e + 1], T());
                 pf[s] = pk.f;
             }
 #pragma unroll
@@ -292,7 +307,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnMfmaArgs a)
                 for (int r = 0; r < 16; ++r) o[u][p][r] *= alpha;
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
-                    o[u][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[p][s], pf[s], o[u][p], 0, 0, 0);
+                    o[u][p] = AttMma<T>::run(vf[p][s], pf[s], o[u][p]);
             }
         }
     }
@@ -310,8 +325,8 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnMfmaArgs a)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     *reinterpret_cast<uint2*>(yb + p * pstride + (long long)q * 64 + (8 * g + 4 * h) * 2) =
-                        make_uint2(pack_bf16x2(o[u][p][4 * g] * inv, o[u][p][4 * g + 1] * inv),
-                                   pack_bf16x2(o[u][p][4 * g + 2] * inv, o[u][p][4 * g + 3] * inv));
+                        make_uint2(pack2(o[u][p][4 * g] * inv, o[u][p][4 * g + 1] * inv, T()),
+                                   pack2(o[u][p][4 * g + 2] * inv, o[u][p][4 * g + 3] * inv, T()));
         }
     }
     if (qt == 0 || qt == a.ntq - 1) {                       // halo rows of this head's planes
@@ -327,7 +342,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnMfmaArgs a)
     }
 }
 
-template <int TQ, int DP>
+template <typename T, int TQ, int DP>
 static int launch_attn_mfma(const adk_op& op, hipStream_t st)
 {
     AttnMfmaArgs a;
@@ -336,7 +351,7 @@ static int launch_attn_mfma(const adk_op& op, hipStream_t st)
     a.heads = op.Cin / (32 * DP); a.ntq = (op.L + 32 * TQ - 1) / (32 * TQ);
     a.nitems = op.B * a.heads * a.ntq;
     const size_t lds = 4 * 2 * DP * ATT_VBUF;
-    hipLaunchKernelGGL((attn_mfma_kernel<TQ, DP>), dim3((a.nitems + 3) / 4), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((attn_mfma_kernel<T, TQ, DP>), dim3((a.nitems + 3) / 4), dim3(256), lds, st, a);
     return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
 }
 
@@ -352,13 +367,20 @@ static int launch_attn_valu(const adk_op& op, hipStream_t st)
     return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
 }
 
+template <typename T>
+static int launch_attn_16(const adk_op& op, hipStream_t st, bool d64)
+{
+    if (op.P * 4 <= 64) {
+        if (d64) return op.L >= 512 ? launch_attn_mfma<T, 2, 2>(op, st) : launch_attn_mfma<T, 1, 2>(op, st);
+        return op.L >= 512 ? launch_attn_mfma<T, 2, 1>(op, st) : launch_attn_mfma<T, 1, 1>(op, st);
+    }
+    return d64 ? launch_attn_valu<T, 64>(op, st) : launch_attn_valu<T, 32>(op, st);
+}
+
 int launch_attn(const adk_op& op, hipStream_t st)
 {
     const bool d64 = op.i0 == 64;                           // head dim: op.i0 (0 = 32)
-    if (op.dtype == ADK_BF16 && op.P * 4 <= 64) {
-        if (d64) return op.L >= 512 ? launch_attn_mfma<2, 2>(op, st) : launch_attn_mfma<1, 2>(op, st);
-        return op.L >= 512 ? launch_attn_mfma<2, 1>(op, st) : launch_attn_mfma<1, 1>(op, st);
-    }
     if (op.dtype == ADK_F32) return d64 ? launch_attn_valu<float, 64>(op, st) : launch_attn_valu<float, 32>(op, st);
-    return d64 ? launch_attn_valu<bf16_t, 64>(op, st) : launch_attn_valu<bf16_t, 32>(op, st);
+    if (op.dtype == ADK_F16) return launch_attn_16<f16_t>(op, st, d64);
+    return launch_attn_16<bf16_t>(op, st, d64);
 }

@@ -19,6 +19,12 @@ template <> struct Mma<bf16_t> {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
 };
+template <> struct Mma<f16_t> {
+    typedef f16x8 Frag;
+    static __device__ __forceinline__ void run(const Frag& a, const Frag& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
 template <> struct Mma<float> {
     typedef f32x4 Frag;
     static __device__ __forceinline__ void run(const Frag& a, const Frag& b, f32x16& c) {
@@ -38,6 +44,14 @@ __device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
 }
 __device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
     *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+}
+__device__ __forceinline__ void store4(f16_t* p, const float (&v)[4]) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack2(v[0], v[1], f16_t()), pack2(v[2], v[3], f16_t()));
+}
+__device__ __forceinline__ void load4(const f16_t* p, float (&v)[4]) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    const f32x2 a = unpack2(t.x, f16_t()), b = unpack2(t.y, f16_t());
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
 }
 __device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
     const float4 t = *reinterpret_cast<const float4*>(p);

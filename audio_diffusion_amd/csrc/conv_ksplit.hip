@@ -223,6 +223,8 @@ static int launch_ks_taps(const adk_op& op, hipStream_t st)
 int launch_conv_ksplit(const adk_op& op, hipStream_t st)
 {
     if (op.dtype == ADK_F32) return launch_ks_taps<float, float>(op, st);
+    if (op.dtype == ADK_F16)
+        return (op.flags & ADK_FLAG_OUT_F32) ? launch_ks_taps<f16_t, float>(op, st) : launch_ks_taps<f16_t, f16_t>(op, st);
     if (op.flags & ADK_FLAG_OUT_F32) return launch_ks_taps<bf16_t, float>(op, st);
     return launch_ks_taps<bf16_t, bf16_t>(op, st);
 }

@@ -81,6 +81,8 @@ int launch_conv(const adk_op& op, hipStream_t st)
     if (ct.ksplit) return launch_conv_ksplit(op, st);
     if ((op.flags & (ADK_FLAG_CAUSAL | ADK_FLAG_ELU | ADK_FLAG_GROUP_STATS)) || op.i0 > 1) return launch_conv_ext(op, st);
     if (op.dtype == ADK_F32) return launch_taps<float, float>(op, st);
+    if (op.dtype == ADK_F16)
+        return (op.flags & ADK_FLAG_OUT_F32) ? launch_taps<f16_t, float>(op, st) : launch_taps<f16_t, f16_t>(op, st);
     if (op.flags & ADK_FLAG_OUT_F32) return launch_taps<bf16_t, float>(op, st);
     return launch_taps<bf16_t, bf16_t>(op, st);
 }

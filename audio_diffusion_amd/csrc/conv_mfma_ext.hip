@@ -19,6 +19,8 @@ static int launch_taps_ext(const adk_op& op, hipStream_t st)
 int launch_conv_ext(const adk_op& op, hipStream_t st)
 {
     if (op.dtype == ADK_F32) return launch_taps_ext<float, float>(op, st);
+    if (op.dtype == ADK_F16)
+        return (op.flags & ADK_FLAG_OUT_F32) ? launch_taps_ext<f16_t, float>(op, st) : launch_taps_ext<f16_t, f16_t>(op, st);
     if (op.flags & ADK_FLAG_OUT_F32) return launch_taps_ext<bf16_t, float>(op, st);
     return launch_taps_ext<bf16_t, bf16_t>(op, st);
 }

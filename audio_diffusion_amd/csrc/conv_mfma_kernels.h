@@ -11,7 +11,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
 {
     constexpr int CBO = ElemTraits<TO>::CB;
     // ---- epilogue: lane (l31, h) holds D[co = 8g + 4h + e][pos = l31] in acc[..][4g + e] ----
-    // bf16 output: the two half-waves hold the two 8-byte halves of one 16-byte piece, so channel groups are
+    // 16-bit output: the two half-waves hold the two 8-byte halves of one 16-byte piece, so channel groups are
     // processed in pairs (g, g+1) and exchanged with v_permlane32_swap: lanes h=0 then store channels
     // 8g..8g+7, lanes h=1 channels 8g+8..8g+15, as ONE 16-byte store each (half the store instructions:
     // the tail of this kernel is store-issue bound, not bandwidth bound).
@@ -29,7 +29,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
 #pragma unroll
         for (int i = 0; i < TCO; ++i) {
             const int co32 = cobase + (wco * TCO + i) * 32;
-            const bool ok = lvalid && co32 < a.Cout_alloc;      // Cout_alloc is a multiple of 32 when TO = bf16
+            const bool ok = lvalid && co32 < a.Cout_alloc;      // Cout_alloc is a multiple of 32 when TO is 16-bit
 #pragma unroll
             for (int g0 = 0; g0 < 4; g0 += 2) {
                 float v[2][4];
@@ -64,8 +64,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
                     }
                 }
                 if constexpr (sizeof(TO) == 2) {
-                    uint32_t ax = pack_bf16x2(v[0][0], v[0][1]), ay = pack_bf16x2(v[0][2], v[0][3]);
-                    uint32_t bx = pack_bf16x2(v[1][0], v[1][1]), by = pack_bf16x2(v[1][2], v[1][3]);
+                    uint32_t ax = pack2(v[0][0], v[0][1], TO()), ay = pack2(v[0][2], v[0][3], TO());
+                    uint32_t bx = pack2(v[1][0], v[1][1], TO()), by = pack2(v[1][2], v[1][3], TO());
                     // swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second (all lanes active here)
                     const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
                     const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);

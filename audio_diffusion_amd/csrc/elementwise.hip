@@ -103,6 +103,7 @@ int launch_pack_input(const adk_op& op, hipStream_t st)
     a.nplanes = Cp / CB;
     dim3 grid((a.Lp + 255) / 256, a.nplanes, op.B);
     if (op.dtype == ADK_F32) hipLaunchKernelGGL(pack_input_kernel<float>, grid, dim3(256), 0, st, a);
+    else if (op.dtype == ADK_F16) hipLaunchKernelGGL(pack_input_kernel<f16_t>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(pack_input_kernel<bf16_t>, grid, dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
 }

@@ -1,5 +1,5 @@
 // GroupNorm(1,C) apply + GELU + residual add, one HBM-bound pass over a chunk-plane tensor.
-// GELU is the exact erf form: erff in the f32 path, a 1.5e-7-accurate erf in the bf16 path (adk_common.h).
+// GELU is the exact erf form: erff in the f32 path, a 2e-7-accurate single-exp2 form in the bf16 path (adk_common.h).
 //
 // Replaces nn.GroupNorm(1,C) -> nn.GELU() -> (+ skip) of ResConvBlock (reference blocks/blocks.py:71-75,
 // 14-15) and the norm of SelfAttention1d (:107,115).  The per-sample statistics arrive as (sum, sumsq)
@@ -25,7 +25,26 @@ struct GnArgs {
     int mod_stride; float ada;                   // AdaGN: gamma/beta rows per sample (floats), ada = 1 (scale = gamma + 1)
 };
 
-template <typename T, bool GELU, bool APPLY>
+// gelu_fast (adk_common.h) on a pair: the polynomial, the products and the final subtraction are packed-f32
+// instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two elements per issue slot); min, max and exp2 are not.
+// r = (u / 2) E uses the clamped u: beyond the clamp E <= 1.2e-9, so the difference is below 4e-9.
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 v) {
+    f32x2 u;
+    u.x = fminf(fabsf(v.x), 6.08f); u.y = fminf(fabsf(v.y), 6.08f);
+    f32x2 q = u * -3.224038610e-05f + 7.605187619e-04f;
+    q = q * u + -8.046323462e-03f;
+    q = q * u + 5.334470532e-02f;
+    q = q * u + 4.588402605e-01f;
+    q = q * u + 1.151166223e+00f;
+    const f32x2 t = u * q;
+    f32x2 e;
+    e.x = __builtin_amdgcn_exp2f(-t.x); e.y = __builtin_amdgcn_exp2f(-t.y);
+    f32x2 m;
+    m.x = fmaxf(v.x, 0.f); m.y = fmaxf(v.y, 0.f);
+    return m - (u * 0.5f) * e;
+}
+
+template <typename T, bool GELU, bool APPLY, bool STATS, bool RES>
 __global__ __launch_bounds__(256) void gn_kernel(const GnArgs a)
 {
     constexpr int NV = ElemTraits<T>::NV, CB = ElemTraits<T>::CB;
@@ -50,30 +69,54 @@ __global__ __launch_bounds__(256) void gn_kernel(const GnArgs a)
     }
     const long long rowbase = (long long)plane * a.M + (long long)b * a.Lp;
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x) + rowbase * 64 + q * 16;
-    const unsigned char* rbp = a.residual ? reinterpret_cast<const unsigned char*>(a.residual) + rowbase * 64 + q * 16 : nullptr;
+    const unsigned char* rbp = RES ? reinterpret_cast<const unsigned char*>(a.residual) + rowbase * 64 + q * 16 : nullptr;
     unsigned char* yb = APPLY ? reinterpret_cast<unsigned char*>(a.y) + rowbase * 64 + q * 16 : nullptr;
 
     const int lbeg = rb * a.RB, lend = (lbeg + a.RB < a.L) ? lbeg + a.RB : a.L;
     float s1 = 0.f, s2 = 0.f;
     auto body = [&](const uint4& xin, const uint4& rin, long long ro) {
-        float f[NV];
-        piece_to_float(xin, f, T());
-        if (APPLY) {
+        if constexpr (sizeof(T) == 2) {              // bf16 / f16: pairs, packed-f32 arithmetic
+            const uint32_t w[4] = {xin.x, xin.y, xin.z, xin.w};
+            const uint32_t rw[4] = {rin.x, rin.y, rin.z, rin.w};
+            uint32_t o[4];
 #pragma unroll
-            for (int e = 0; e < NV; ++e) {
-                float v = f[e] * scale[e] + shift[e];
-                f[e] = GELU ? gelu_for<T>(v) : v;
+            for (int i = 0; i < 4; ++i) {
+                f32x2 v = unpack2(w[i], T());
+                if (APPLY) {
+                    f32x2 sc, sh;
+                    sc.x = scale[2 * i]; sc.y = scale[2 * i + 1]; sh.x = shift[2 * i]; sh.y = shift[2 * i + 1];
+                    v = v * sc + sh;
+                    if (GELU) v = gelu_fast2(v);
+                    if (RES) {
+                        v += unpack2(rw[i], T());
+                    }
+                    o[i] = pack2(v.x, v.y, T());
+                }
+                if (STATS) { s1 += v.x; s2 += v.x * v.x; s1 += v.y; s2 += v.y * v.y; }
             }
-            if (rbp) {
-                float r[NV];
-                piece_to_float(rin, r, T());
+            if (APPLY) *reinterpret_cast<uint4*>(yb + ro) = make_uint4(o[0], o[1], o[2], o[3]);
+        } else {
+            float f[NV];
+            piece_to_float(xin, f, T());
+            if (APPLY) {
 #pragma unroll
-                for (int e = 0; e < NV; ++e) f[e] += r[e];
+                for (int e = 0; e < NV; ++e) {
+                    float v = f[e] * scale[e] + shift[e];
+                    f[e] = GELU ? gelu_for<T>(v) : v;
+                }
+                if (RES) {
+                    float r[NV];
+                    piece_to_float(rin, r, T());
+#pragma unroll
+                    for (int e = 0; e < NV; ++e) f[e] += r[e];
+                }
+                *reinterpret_cast<uint4*>(yb + ro) = float_to_piece(f, T());
             }
-            *reinterpret_cast<uint4*>(yb + ro) = float_to_piece(f, T());
+            if (STATS) {
+#pragma unroll
+                for (int e = 0; e < NV; ++e) { s1 += f[e]; s2 += f[e] * f[e]; }
+            }
         }
-#pragma unroll
-        for (int e = 0; e < NV; ++e) { s1 += f[e]; s2 += f[e] * f[e]; }
     };
     constexpr int U = 4;                             // independent 16-byte loads in flight per thread
     int l = lbeg + r0;
@@ -83,7 +126,7 @@ __global__ __launch_bounds__(256) void gn_kernel(const GnArgs a)
         for (int u = 0; u < U; ++u) {
             const long long ro = (long long)(a.P + l + 64 * u) * 64;
             xin[u] = *reinterpret_cast<const uint4*>(xb + ro);
-            rin[u] = rbp ? *reinterpret_cast<const uint4*>(rbp + ro) : make_uint4(0, 0, 0, 0);
+            rin[u] = RES ? *reinterpret_cast<const uint4*>(rbp + ro) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) body(xin[u], rin[u], (long long)(a.P + l + 64 * u) * 64);
@@ -91,7 +134,7 @@ __global__ __launch_bounds__(256) void gn_kernel(const GnArgs a)
     for (; l < lend; l += 64) {
         const long long ro = (long long)(a.P + l) * 64;
         const uint4 xin = *reinterpret_cast<const uint4*>(xb + ro);
-        const uint4 rin = rbp ? *reinterpret_cast<const uint4*>(rbp + ro) : make_uint4(0, 0, 0, 0);
+        const uint4 rin = RES ? *reinterpret_cast<const uint4*>(rbp + ro) : make_uint4(0, 0, 0, 0);
         body(xin, rin, ro);
     }
     if (APPLY && (rb == 0 || rb == a.nrb - 1)) {      // halo rows of the output
@@ -101,7 +144,7 @@ __global__ __launch_bounds__(256) void gn_kernel(const GnArgs a)
             if (rb == a.nrb - 1) *reinterpret_cast<uint4*>(yb + (long long)(a.P + a.L + r) * 64) = z;
         }
     }
-    if (a.partials_out) {
+    if (STATS) {
         float* redf = reinterpret_cast<float*>(red);
         block_sum2(s1, s2, redf);
         if (tid == 0) {
@@ -138,13 +181,27 @@ static int launch_gn_t(const adk_op& op, hipStream_t st, bool apply)
     a.mod_stride = (op.flags & ADK_FLAG_ADA) ? op.i0 : 0;
     a.ada = (op.flags & ADK_FLAG_ADA) ? 1.f : 0.f;
     dim3 grid(a.nrb, a.nplanes, op.B);
-    if (!apply) hipLaunchKernelGGL((gn_kernel<T, false, false>), grid, dim3(256), 0, st, a);
-    else if (op.flags & ADK_FLAG_GELU) hipLaunchKernelGGL((gn_kernel<T, true, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gn_kernel<T, false, true>), grid, dim3(256), 0, st, a);
+    // compile-time variants: the (sum, sumsq) of the output cost 2 VALU ops per element, a runtime residual test a
+    // branch per 16-byte piece
+    const bool stats = a.partials_out != nullptr, res = a.residual != nullptr, gelu = (op.flags & ADK_FLAG_GELU) != 0;
+#define ADK_GN_LAUNCH(G_, A_, S_, R_) hipLaunchKernelGGL((gn_kernel<T, G_, A_, S_, R_>), grid, dim3(256), 0, st, a)
+    if (!apply) {
+        if (!stats) return ADK_EINVAL;
+        ADK_GN_LAUNCH(false, false, true, false);
+    } else if (gelu) {
+        if (stats) { if (res) ADK_GN_LAUNCH(true, true, true, true); else ADK_GN_LAUNCH(true, true, true, false); }
+        else       { if (res) ADK_GN_LAUNCH(true, true, false, true); else ADK_GN_LAUNCH(true, true, false, false); }
+    } else {
+        if (stats) { if (res) ADK_GN_LAUNCH(false, true, true, true); else ADK_GN_LAUNCH(false, true, true, false); }
+        else       { if (res) ADK_GN_LAUNCH(false, true, false, true); else ADK_GN_LAUNCH(false, true, false, false); }
+    }
+#undef ADK_GN_LAUNCH
     return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
 }
 
 int launch_gn(const adk_op& op, hipStream_t st, bool apply)
 {
-    return op.dtype == ADK_F32 ? launch_gn_t<float>(op, st, apply) : launch_gn_t<bf16_t>(op, st, apply);
+    if (op.dtype == ADK_F32) return launch_gn_t<float>(op, st, apply);
+    if (op.dtype == ADK_F16) return launch_gn_t<f16_t>(op, st, apply);
+    return launch_gn_t<bf16_t>(op, st, apply);
 }

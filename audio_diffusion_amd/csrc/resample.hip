@@ -138,6 +138,7 @@ static int launch_fir_t(const adk_op& op, hipStream_t st)
 int launch_fir(const adk_op& op, hipStream_t st, bool up)
 {
     if (op.dtype == ADK_F32) return up ? launch_fir_t<float, true>(op, st) : launch_fir_t<float, false>(op, st);
+    if (op.dtype == ADK_F16) return up ? launch_fir_t<f16_t, true>(op, st) : launch_fir_t<f16_t, false>(op, st);
     return up ? launch_fir_t<bf16_t, true>(op, st) : launch_fir_t<bf16_t, false>(op, st);
 }
 

@@ -323,7 +323,7 @@ class AudioDenoiserModel(nn.Module):
     def resolve_dtype(self):
         if self.compute_dtype is not None:
             return self.compute_dtype
-        return torch.bfloat16 if torch.is_autocast_enabled() else torch.float32
+        return _lib.autocast_dtype() if torch.is_autocast_enabled() else torch.float32
 
     def plan_for(self, B, L, dtype, device, cond_len=0, log_sigma=True, has_mapping_cond=False, scaled=False):
         key = (B, L, dtype, str(device), cond_len, log_sigma, has_mapping_cond, scaled)

@@ -1,7 +1,7 @@
 """Chunk-plane layout (CPL) <-> [B, C, L] conversion with torch ops (plumbing for tests, debugging and
 callers that want to feed libadk kernels directly; the denoiser itself packs/unpacks in HIP kernels).
 
-CPL: element (b, c, l) at (((c // CB) * B + b) * (L + 2P) + P + l) * CB + c % CB, CB = 16 (f32) / 32 (bf16);
+CPL: element (b, c, l) at (((c // CB) * B + b) * (L + 2P) + P + l) * CB + c % CB, CB = 16 (f32) / 32 (bf16, f16);
 halo rows and pad channels are zero.  See include/adk.h.
 """
 import torch

@@ -190,7 +190,7 @@ def _sample(model, x, steps, eta, warp, extra_args):
     prev = getattr(model, "compute_dtype", None)
     auto = isinstance(model, DiffusionAttnUnet1D) and prev is None
     if auto:
-        model.compute_dtype = torch.bfloat16       # the reference wraps the call in autocast (:30)
+        model.compute_dtype = model.resolve_dtype(in_sampler=True)      # the reference wraps the call in autocast (:30)
     try:
         for i in range(steps):
             v = model(xs, ts * coef[i, 0].item(), **extra_args).float().contiguous()

@@ -201,7 +201,7 @@ class _SSBase(nn.Module):
         if x.dim() != 3 or x.shape[1] != channels_in:
             raise RuntimeError(f"expected {what} of shape [B, {channels_in}, L], got {tuple(x.shape)} "
                                "(the reference fails in its first conv with a channel mismatch)")
-        dtype = self.compute_dtype or (torch.bfloat16 if torch.is_autocast_enabled() else torch.float32)
+        dtype = self.compute_dtype or (_lib.autocast_dtype() if torch.is_autocast_enabled() else torch.float32)
         xin = x.detach().to(torch.float32).contiguous()
         plan = self.plan_for(x.shape[0], x.shape[2], dtype, x.device)
         out = torch.empty(x.shape[0], channels_out, out_len, dtype=torch.float32, device=x.device)

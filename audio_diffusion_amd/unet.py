@@ -77,7 +77,7 @@ class _Plan:
         self.model, self.B, self.T, self.device = model, B, T, device
         self.cond_len = cond_len          # 0: no cond input; else length of the [B, cond_dim, cond_len] tensor
         self.dtype = dtype
-        self.adk_dtype = _lib.ADK_F32 if dtype == torch.float32 else _lib.ADK_BF16
+        self.adk_dtype = _lib.adk_dtype(dtype)
         self.CB = 16 if dtype == torch.float32 else 32
         self.P = getattr(model, "halo_rows", None) or model.kernel_size // 2
         self.planner = _ArenaPlanner()
@@ -512,7 +512,7 @@ class DiffusionAttnUnet1D(nn.Module):
             for param in self.net.parameters():
                 param *= 0.5
 
-        self.compute_dtype = None      # None: fp32 for direct calls (bf16 under torch.autocast), bf16 inside sample()
+        self.compute_dtype = None      # None: fp32 for direct calls (bf16 / f16 under torch.autocast), bf16 inside sample()
         self._wcache = {}
         self._plans = {}
 
@@ -564,9 +564,9 @@ class DiffusionAttnUnet1D(nn.Module):
     def resolve_dtype(self, in_sampler=False):
         if self.compute_dtype is not None:
             return self.compute_dtype
-        if in_sampler or torch.is_autocast_enabled():
-            return torch.bfloat16
-        return torch.float32
+        if torch.is_autocast_enabled():
+            return _lib.autocast_dtype()
+        return torch.bfloat16 if in_sampler else torch.float32
 
     def plan_for(self, B, T, dtype, device, t_table=None, cond_len=0):
         key = (B, T, dtype, str(device), t_table, cond_len)

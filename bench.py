@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: audio-seconds generated per second, 2^16-sample stereo, 100-step v-DDIM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--batch 16] [--ddim-steps 100]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|f16|fp32] [--batch 16] [--ddim-steps 100]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is ONE pass of the hot path over one batch: ``sample(model, x[B,2,65536], 100, eta=0)`` on the
@@ -28,7 +28,8 @@ sys.path.insert(0, ROOT)
 
 SAMPLE_RATE = 48000          # reference defaults.ini:41
 T = 65536                    # reference defaults.ini:23
-PEAK = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA TFLOP/s (MI355X_MICROARCH.md)
+PEAK = {"bf16": 2500.0, "f16": 2500.0, "fp32": 157.3}     # dense MFMA TFLOP/s (MI355X_MICROARCH.md)
+DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "fp32": torch.float32}
 
 
 def build_model():
@@ -86,7 +87,7 @@ def conv_roofline(model, B, dtype, dev, reps=3):
         if r:                                        # first pass is a warm-up
             for i, (e0, e1) in evs.items():
                 ms[i] += e0.elapsed_time(e1) / reps
-    key = "bf16" if dtype == torch.bfloat16 else "fp32"
+    key = {v: k for k, v in DTYPES.items()}[dtype]
     per = {}
     for pt, idx in groups.items():
         fl = sum(plan.meta[i]["flops"] for i in idx)
@@ -141,7 +142,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "fp32"])
     ap.add_argument("--batch", type=int, default=16, help="samples per GPU")
     ap.add_argument("--ddim-steps", type=int, default=100)
     ap.add_argument("--cpu-calls", type=int, default=4, help="denoiser calls timed for cpu_baseline (0 = skip)")
@@ -160,7 +161,7 @@ def main():
     torch.cuda.set_device(dev)
     if world > 1:
         D.init(rank, world)
-    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dtype = DTYPES[a.dtype]
 
     model = build_model()
     cpu = None

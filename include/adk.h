@@ -32,6 +32,8 @@ extern "C" {
 
 #define ADK_F32 0
 #define ADK_BF16 1
+#define ADK_F16 2              /* IEEE half: same layout (CB = 32), kernels and MFMA rate as bf16; the dtype of the
+                                  reference's own autocast region (diffusion/sampling.py:30) */
 
 /* op kinds for adk_op / adk_run_plan */
 enum {

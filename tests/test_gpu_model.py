@@ -59,6 +59,26 @@ def test_tiny_forward_bf16(name):
 
 
 @pytest.mark.parametrize("name", TINY)
+def test_tiny_forward_f16(name):
+    """IEEE half (ADK_F16), the dtype of the reference's own autocast region (diffusion/sampling.py:30): three more
+    mantissa bits than bf16, so the north_star's reduced-precision bound of 1e-2 per denoiser call holds with margin."""
+    dev = torch.device("cuda:0")
+    z = load_npz(name)
+    m = build(z, dev)
+    m.compute_dtype = torch.float16
+    x, t = torch.from_numpy(z["x"]).to(dev), torch.from_numpy(z["t"]).to(dev)
+    y = m(x, t)
+    ref = torch.from_numpy(z["y"])
+    assert y.dtype == torch.float32 and torch.isfinite(y).all()
+    assert rel_err(y, ref) <= 1e-2                       # measured 1.8e-3 .. 3.5e-3 (profiles/r01/v9_dtype_error.txt)
+    assert float((y.cpu().double() - ref.double()).norm() / ref.double().norm()) <= 5e-3
+    assert torch.equal(y, m(x, t))                       # deterministic
+    m.compute_dtype = None                               # under the reference's autocast the dtype follows the region
+    with torch.autocast("cuda", dtype=torch.float16):
+        assert torch.equal(m(x, t), y)
+
+
+@pytest.mark.parametrize("name", TINY)
 @pytest.mark.parametrize("graph", [False, True])
 def test_tiny_sample_fp32(name, graph):
     import audio_diffusion_amd as A
@@ -128,6 +148,11 @@ def test_full_model_first_call_and_10_steps():
     m.compute_dtype = torch.bfloat16
     v0b = m(x, torch.ones(1, device=dev))
     assert rel_err(v0b, ref_v0) <= 2e-2
+    m.compute_dtype = torch.float16                      # the reference's autocast dtype: within the north_star's 1e-2
+    v0h = m(x, torch.ones(1, device=dev))
+    assert rel_err(v0h, ref_v0) <= 5e-3                  # measured 1.9e-3 (bf16: 1.6e-2)
+    predh = A.sample(m, x, 10, 0)
+    assert torch.isfinite(predh).all() and snr_db(predh, ref) >= 60.0      # measured 79 dB: the fp32 bar, in half
 
 
 def test_crash_schedule_sampler_and_int16_output_stage():

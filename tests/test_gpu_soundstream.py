@@ -83,7 +83,7 @@ def test_default_architecture_vs_oracle():
     assert float((m(lat.to(DEV)).cpu() - want).norm() / want.norm()) <= 3e-2
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("C,Co,L,dil", [(32, 32, 300, 1), (32, 32, 1000, 9), (64, 64, 70, 3), (64, 128, 700, 9),
                                          (128, 128, 3000, 3), (256, 256, 40, 9), (128, 128, 200, 1)])
 def test_dilated_causal_conv_elu(dtype, C, Co, L, dil):
@@ -92,7 +92,7 @@ def test_dilated_causal_conv_elu(dtype, C, Co, L, dil):
     lib = _lib.load()
     torch.manual_seed(C + L + dil)
     B, P, cb = 2, 54, 16 if dtype == torch.float32 else 32
-    adt = _lib.ADK_F32 if dtype == torch.float32 else _lib.ADK_BF16
+    adt = _lib.adk_dtype(dtype)
     x = torch.randn(B, C, L, device=DEV)
     w = torch.randn(Co, C, 7, device=DEV) * (C * 7) ** -0.5
     bias, res = torch.randn(Co, device=DEV), torch.randn(B, Co, L, device=DEV)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-op HIP-event timing of one denoiser call (eager, op by op), aggregated by kind / level.
-usage: python tools/profile_ops.py [--dtype bf16|fp32] [--batch 16] [--reps 3]"""
+usage: python tools/profile_ops.py [--dtype bf16|f16|fp32] [--batch 16] [--reps 3]"""
 import argparse
 import ctypes
 import os
@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--model", default="uncond", help="uncond (config 2) | k-audio (k_audio_uncond_long_1.json, B=4, 32 x 32768)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "fp32": torch.float32}[a.dtype]
     torch.manual_seed(0)
     if a.model == "k-audio":
         a.batch = 4 if a.batch == 16 else a.batch

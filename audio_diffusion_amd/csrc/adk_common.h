@@ -51,7 +51,13 @@ __device__ __forceinline__ void piece_to_float(const uint4& p, float (&f)[8], bf
     }
 }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    // plain casts: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
+    // plain casts: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving) per element and merges the halves.
+    // Do NOT "improve" this into one vector conversion per pair inside the conv epilogues: with a single
+    // in-place v_cvt_pk_bf16_f32 per pair there, the (sum, sumsq) partials of the same registers came out different
+    // from run to run in 1-4 of 4096 blocks (tools/find_nondeterminism.py; y itself stayed bit-identical) - an
+    // issue-timing dependent hazard this instruction mix avoids.  pack2v below is the one-instruction form, used by
+    // the GroupNorm pass only (its statistics are taken before the conversion in separate registers; verified
+    // bit-reproducible with the same tool).
     union { bf16_t h[2]; uint32_t u; } cv;
     cv.h[0] = (bf16_t)lo; cv.h[1] = (bf16_t)hi;
     return cv.u;
@@ -71,6 +77,16 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi, bf16_t) { return p
 __device__ __forceinline__ uint32_t pack2(float lo, float hi, f16_t) {
     union { f16_t h[2]; uint32_t u; } cv;       // plain casts: round to nearest even (not v_cvt_pkrtz)
     cv.h[0] = (f16_t)lo; cv.h[1] = (f16_t)hi;
+    return cv.u;
+}
+__device__ __forceinline__ uint32_t pack2v(f32x2 v, bf16_t) {
+    union { bf16x2 h; uint32_t u; } cv;
+    cv.h = __builtin_convertvector(v, bf16x2);
+    return cv.u;
+}
+__device__ __forceinline__ uint32_t pack2v(f32x2 v, f16_t) {
+    union { f16x2 h; uint32_t u; } cv;
+    cv.h = __builtin_convertvector(v, f16x2);
     return cv.u;
 }
 __device__ __forceinline__ void piece_to_float(const uint4& p, float (&f)[8], f16_t) {

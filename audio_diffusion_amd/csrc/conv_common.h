@@ -64,6 +64,19 @@ __device__ __forceinline__ void load4(const bf16_t* p, float (&v)[4]) {
 }
 
 
+// raw (unconverted) 4-element piece of an output-typed tensor: lets loads be issued without waiting for their data
+template <typename TO> struct RawVec4 { typedef uint2 type; };
+template <> struct RawVec4<float> { typedef float4 type; };
+__device__ __forceinline__ void raw_to_float4(const float4& t, float (&v)[4], float) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+__device__ __forceinline__ void raw_to_float4(const uint2& t, float (&v)[4], bf16_t) {
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+__device__ __forceinline__ void raw_to_float4(const uint2& t, float (&v)[4], f16_t) {
+    const f32x2 a = unpack2(t.x, f16_t()), b = unpack2(t.y, f16_t());
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+}
+
 // tile shape chosen on the host for one conv op (conv_mfma.hip: conv_tile)
 struct ConvTile { int bn, bm; bool ksplit; };
 ConvTile conv_tile(const adk_op& op);

@@ -86,3 +86,9 @@ int launch_conv(const adk_op& op, hipStream_t st)
     if (op.flags & ADK_FLAG_OUT_F32) return launch_taps<bf16_t, float>(op, st);
     return launch_taps<bf16_t, bf16_t>(op, st);
 }
+
+#ifdef ADK_ABL_TS
+extern "C" int adk_exp_ts(void* dst, size_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_adk_ts), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif

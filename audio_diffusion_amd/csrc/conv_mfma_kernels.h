@@ -4,10 +4,10 @@
 #pragma once
 #include "conv_common.h"
 
-template <bool EXT, typename TO, int BN, int BM, int WPOS, int TCO, int TPOS>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TCO][TPOS], unsigned char* smem,
-                                              int b, int t, int cot, int cobase, int l0, int tid, int l31, int h,
-                                              int wco, int wpos)
+template <bool EXT, bool RES, typename TO, int BN, int BM, int WPOS, int TCO, int TPOS>
+__device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16 (&acc)[TCO][TPOS], unsigned char* smem,
+                                                   int b, int t, int cot, int cobase, int l0, int tid, int l31, int h,
+                                                   int wco, int wpos)
 {
     constexpr int CBO = ElemTraits<TO>::CB;
     // ---- epilogue: lane (l31, h) holds D[co = 8g + 4h + e][pos = l31] in acc[..][4g + e] ----
@@ -21,11 +21,42 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
     float gs1[TCO], gs2[TCO];                                    // per 32-channel group (ADK_FLAG_GROUP_STATS)
 #pragma unroll
     for (int i = 0; i < TCO; ++i) { gs1[i] = 0.f; gs2[i] = 0.f; }
+    // All loads of the epilogue are issued BEFORE its first store.  On gfx9 loads and stores share one in-order
+    // counter (vmcnt), so a bias / residual load issued after a store cannot be waited for without also waiting for
+    // that store's write acknowledgement (~1 us under load): with the loads interleaved per channel group the
+    // epilogue ran as 16-32 serial round trips and took as long as the K loop of a 128-channel level
+    // (per-block timestamps: 13 us of 25).
+    float4 bb[TCO][4];
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            bb[i][g] = a.bias ? *reinterpret_cast<const float4*>(a.bias + cobase + (wco * TCO + i) * 32 + 8 * g + 4 * h)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < TPOS; ++j) {
         const int l = l0 + (wpos * TPOS + j) * 32 + l31;
+#ifdef ADK_ABL_NOSTORE
+        const bool lvalid = l < a.L && a.B < 0;
+#else
         const bool lvalid = l < a.L;
+#endif
         const long long m = (long long)b * a.Lp + a.P + l;
+        // this position's residual pieces: raw loads first (one round trip), conversion at the point of use; lanes
+        // outside the tensor read a valid address of their own sample and discard it
+        typedef typename RawVec4<TO>::type Raw4;
+        Raw4 rraw[TCO][4];
+        if constexpr (RES) {
+            const long long msafe = lvalid ? m : (long long)b * a.Lp + a.P;
+#pragma unroll
+            for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    int co = cobase + (wco * TCO + i) * 32 + 8 * g + 4 * h;
+                    co = co < a.Cout_alloc ? co : 4 * h;
+                    rraw[i][g] = *reinterpret_cast<const Raw4*>(rg + ((((long long)(co / CBO) * a.M + msafe) * CBO) + (co % CBO)));
+                }
+        }
 #pragma unroll
         for (int i = 0; i < TCO; ++i) {
             const int co32 = cobase + (wco * TCO + i) * 32;
@@ -38,15 +69,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
                     const int co = co32 + 8 * (g0 + gg) + 4 * h;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[gg][e] = acc[i][j][4 * (g0 + gg) + e];
-                    if (a.bias) {
-                        const float4 bb = *reinterpret_cast<const float4*>(a.bias + co);
-                        v[gg][0] += bb.x; v[gg][1] += bb.y; v[gg][2] += bb.z; v[gg][3] += bb.w;
-                    }
+                    const float4 bv = bb[i][g0 + gg];
+                    v[gg][0] += bv.x; v[gg][1] += bv.y; v[gg][2] += bv.z; v[gg][3] += bv.w;
                     if (lvalid && co < a.Cout_alloc) {
                         const long long off = (((long long)(co / CBO) * a.M + m) * CBO) + (co % CBO);
-                        if (rg) {
+                        if constexpr (RES) {
                             float rr[4];
-                            load4(rg + off, rr);
+                            raw_to_float4(rraw[i][g0 + gg], rr, TO());
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[gg][e] += rr[e];
                         }
@@ -70,9 +99,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
                     const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
                     const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
                     if (ok) {
-                        const int co = co32 + 8 * g0 + 8 * h;   // h=0: [own g0 | partner's g0], h=1: [partner's g0+1 | own g0+1]
-                        const long long off = (((long long)(co / CBO) * a.M + m) * CBO) + (co % CBO);
-                        *reinterpret_cast<uint4*>(yg + off) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                        // channels co32 + 8 g0 + 8 h .. +7 (h=0: [own g0 | partner's g0], h=1: [partner's g0+1 | own g0+1]):
+                        // co32 is a multiple of 32 = CBO, so the plane is co32 / 32 and the piece 16 (g0 + h) bytes into the row
+                        unsigned char* dst = reinterpret_cast<unsigned char*>(a.y) +
+                                             ((long long)(co32 >> 5) * a.M + m) * 64 + (g0 + h) * 16;
+                        *reinterpret_cast<uint4*>(dst) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
                     }
                 }
             }
@@ -117,6 +148,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[T
             dst[0] = s1; dst[1] = s2;
         }
     }
+}
+
+// two instantiations: the residual variant keeps its raw residual pieces in registers; the plain one carries none of it
+template <bool EXT, typename TO, int BN, int BM, int WPOS, int TCO, int TPOS>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TCO][TPOS], unsigned char* smem,
+                                              int b, int t, int cot, int cobase, int l0, int tid, int l31, int h,
+                                              int wco, int wpos)
+{
+    if (a.residual)
+        conv_epilogue_impl<EXT, true, TO, BN, BM, WPOS, TCO, TPOS>(a, acc, smem, b, t, cot, cobase, l0, tid, l31, h, wco, wpos);
+    else
+        conv_epilogue_impl<EXT, false, TO, BN, BM, WPOS, TCO, TPOS>(a, acc, smem, b, t, cot, cobase, l0, tid, l31, h, wco, wpos);
 }
 
 // LDS image: plain 64-byte rows filled by LDS-DMA (global_load_lds_dwordx4: 1 KiB = 16 rows per wave
@@ -242,6 +285,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_simple_kernel(const ConvArgs
 // MFMA group:
 //   phase g:  ds_read frags(g, k-step 1) | MFMAs(g, k-step 0) | wait unit g+1 -> s_barrier -> issue unit
 //             g+K (into the slot phase g-1 released) | ds_read frags(g+1, k-step 0) | MFMAs(g, k-step 1)
+#ifdef ADK_ABL_TS
+__device__ unsigned long long g_adk_ts[16384 * 4];
+#define ADK_TS(SLOT_) if (threadIdx.x == 0 && blockIdx.x < 16384) g_adk_ts[blockIdx.x * 4 + (SLOT_)] = wall_clock64();
+#else
+#define ADK_TS(SLOT_)
+#endif
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
@@ -263,6 +312,15 @@ __global__ __launch_bounds__(WCO * WPOS * 64, (WCO * WPOS == 8 ? 1 : 2)) void co
     constexpr int XBYTES = XI * NW * 1024, WBYTES = BN * 64;
     typedef typename Mma<T>::Frag Frag;
 
+    ADK_TS(0)
+#ifdef ADK_ABL_TS
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_adk_ts[blockIdx.x * 4 + 3] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xs = smem;                    // [RX][XBYTES]
     unsigned char* ws = smem + RX * XBYTES;      // [RW][WBYTES]
@@ -274,7 +332,11 @@ __global__ __launch_bounds__(WCO * WPOS * 64, (WCO * WPOS == 8 ? 1 : 2)) void co
     const int b = (int)(r1 / (unsigned)a.tps);
     const int cobase = cot * BN;
     const int l0 = t * BM;
+#ifdef ADK_ABL_HOTX
+    const long long mrow0 = a.P + (long long)(lid & 7u) * BM - (EXT ? a.shift : TAPS / 2);
+#else
     const long long mrow0 = (long long)b * a.Lp + a.P + l0 - (EXT ? a.shift : TAPS / 2);   // EXT: causal / dilated taps
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -388,8 +450,13 @@ __global__ __launch_bounds__(WCO * WPOS * 64, (WCO * WPOS == 8 ? 1 : 2)) void co
 #undef ADK_LOAD_FRAGS
 #undef ADK_MMA_ALL
     __syncthreads();      // all fragment reads done before the epilogue reuses LDS for its reduction
+    ADK_TS(1)
 
     conv_epilogue<EXT, TO, BN, BM, WPOS, TCO, TPOS>(a, acc, smem, b, t, cot, cobase, l0, tid, l31, h, wco, wpos);
+#ifdef ADK_ABL_TS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    ADK_TS(2)
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void gn_kernel(const GnArgs a)
                     if (RES) {
                         v += unpack2(rw[i], T());
                     }
-                    o[i] = pack2(v.x, v.y, T());
+                    o[i] = pack2v(v, T());
                 }
                 if (STATS) { s1 += v.x; s2 += v.x * v.x; s1 += v.y; s2 += v.y * v.y; }
             }

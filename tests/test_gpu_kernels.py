@@ -124,6 +124,36 @@ def test_conv1d(env, dt, case):
     assert float(((s[:, 1] - ref64.pow(2).sum((1, 2))).abs() / ref64.pow(2).sum((1, 2))).max()) <= 1e-4
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("Cin,Cout,L", [(32, 128, 65536), (128, 128, 32768), (256, 256, 8192)])
+def test_conv1d_bits_and_partials_reproducible(env, dt, Cin, Cout, L):
+    """A full-size launch (4096 / 2048 / 1024 blocks, every CU busy) repeated 4 times: output AND (sum, sumsq) partials
+    must be bit-identical.  Regression test: an epilogue variant once produced run-to-run different sumsq partials in
+    1-4 of 4096 blocks while the output stayed identical (see pack_bf16x2 in adk_common.h)."""
+    lib, _lib, layout, dev = env
+    dtype, adk, _ = DT[dt]
+    B, P, taps, cb = 16, 2, 5, 32
+    torch.manual_seed(L)
+    xd = layout.to_cpl(torch.randn(B, Cin, L, device=dev), dtype, P)
+    wd = (torch.randn(Cin // cb, taps, Cout, cb, device=dev) / (Cin * taps) ** 0.5).to(dtype)
+    bd = torch.randn(Cout, device=dev)
+    op = _lib.AdkOp()
+    op.kind, op.dtype, op.L, op.Cout, op.CoutPad, op.Cin, op.B, op.taps = _lib.OP_CONV, adk, L, Cout, Cout, Cin, B, taps
+    npart = lib.adk_partials_count(C.byref(op))
+    outs = []
+    for _ in range(4):
+        yd = torch.zeros(Cout // cb, B, L + 2 * P, cb, dtype=dtype, device=dev)
+        part = torch.zeros(B, npart, 2, device=dev)
+        rc = lib.adk_conv1d(adk, 0, B, L, P, Cin, Cout, Cout, taps, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), None,
+                            yd.data_ptr(), part.data_ptr(), sp())
+        assert rc == 0, lib.adk_last_error()
+        torch.cuda.synchronize()
+        outs.append((yd, part))
+    for yd, part in outs[1:]:
+        assert torch.equal(yd.view(torch.int16), outs[0][0].view(torch.int16)), "output bits differ between runs"
+        assert torch.equal(part.view(torch.int32), outs[0][1].view(torch.int32)), "partials differ between runs"
+
+
 def test_conv1d_rejects_bad_shapes(env):
     lib, _lib, layout, dev = env
     buf = torch.zeros(1 << 16, device=dev)

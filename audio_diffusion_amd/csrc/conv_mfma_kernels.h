@@ -4,6 +4,13 @@
 #pragma once
 #include "conv_common.h"
 
+#ifdef ADK_ABL_TS       // experiment builds only: per-block timestamps (tools: .exp/ts_exp.py)
+__device__ unsigned long long g_adk_ts[16384 * 8];
+#define ADK_TS(SLOT_) if (threadIdx.x == 0 && blockIdx.x < 16384) g_adk_ts[blockIdx.x * 8 + (SLOT_)] = wall_clock64();
+#else
+#define ADK_TS(SLOT_)
+#endif
+
 template <bool EXT, bool RES, typename TO, int BN, int BM, int WPOS, int TCO, int TPOS>
 __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16 (&acc)[TCO][TPOS], unsigned char* smem,
                                                    int b, int t, int cot, int cobase, int l0, int tid, int l31, int h,
@@ -17,10 +24,12 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16 (&a
     // the tail of this kernel is store-issue bound, not bandwidth bound).
     TO* yg = reinterpret_cast<TO*>(a.y);
     const TO* rg = reinterpret_cast<const TO*>(a.residual);
-    float s1 = 0.f, s2 = 0.f;
-    float gs1[TCO], gs2[TCO];                                    // per 32-channel group (ADK_FLAG_GROUP_STATS)
+    // (sum, sumsq) as packed pairs: one v_pk_add_f32 + one v_pk_fma_f32 per two values (the scalar form cost three
+    // instructions per value in moves and half-used packed ops; the epilogue is VALU-bound: 5 of its 7 us)
+    f32x2 s1v = {0.f, 0.f}, s2v = {0.f, 0.f};
+    f32x2 gs1v[TCO], gs2v[TCO];                                  // per 32-channel group (ADK_FLAG_GROUP_STATS)
 #pragma unroll
-    for (int i = 0; i < TCO; ++i) { gs1[i] = 0.f; gs2[i] = 0.f; }
+    for (int i = 0; i < TCO; ++i) { gs1v[i] = s1v; gs2v[i] = s1v; }
     // All loads of the epilogue are issued BEFORE its first store.  On gfx9 loads and stores share one in-order
     // counter (vmcnt), so a bias / residual load issued after a store cannot be waited for without also waiting for
     // that store's write acknowledgement (~1 us under load): with the loads interleaved per channel group the
@@ -33,6 +42,10 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16 (&a
         for (int g = 0; g < 4; ++g)
             bb[i][g] = a.bias ? *reinterpret_cast<const float4*>(a.bias + cobase + (wco * TCO + i) * 32 + 8 * g + 4 * h)
                               : make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef ADK_ABL_TS
+    if (a.bias) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    ADK_TS(4)
+#endif
 #pragma unroll
     for (int j = 0; j < TPOS; ++j) {
         const int l = l0 + (wpos * TPOS + j) * 32 + l31;
@@ -63,38 +76,44 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16 (&a
             const bool ok = lvalid && co32 < a.Cout_alloc;      // Cout_alloc is a multiple of 32 when TO is 16-bit
 #pragma unroll
             for (int g0 = 0; g0 < 4; g0 += 2) {
-                float v[2][4];
+                f32x2 va[2], vb[2];
 #pragma unroll
                 for (int gg = 0; gg < 2; ++gg) {
-                    const int co = co32 + 8 * (g0 + gg) + 4 * h;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[gg][e] = acc[i][j][4 * (g0 + gg) + e];
-                    const float4 bv = bb[i][g0 + gg];
-                    v[gg][0] += bv.x; v[gg][1] += bv.y; v[gg][2] += bv.z; v[gg][3] += bv.w;
+                    const int G = g0 + gg, co = co32 + 8 * G + 4 * h;
+                    const float4 bv = bb[i][G];
+                    va[gg].x = acc[i][j][4 * G]; va[gg].y = acc[i][j][4 * G + 1];
+                    vb[gg].x = acc[i][j][4 * G + 2]; vb[gg].y = acc[i][j][4 * G + 3];
+                    f32x2 b0, b1;
+                    b0.x = bv.x; b0.y = bv.y; b1.x = bv.z; b1.y = bv.w;
+                    va[gg] += b0; vb[gg] += b1;
                     if (lvalid && co < a.Cout_alloc) {
-                        const long long off = (((long long)(co / CBO) * a.M + m) * CBO) + (co % CBO);
                         if constexpr (RES) {
                             float rr[4];
-                            raw_to_float4(rraw[i][g0 + gg], rr, TO());
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[gg][e] += rr[e];
+                            raw_to_float4(rraw[i][G], rr, TO());
+                            f32x2 r0, r1;
+                            r0.x = rr[0]; r0.y = rr[1]; r1.x = rr[2]; r1.y = rr[3];
+                            va[gg] += r0; vb[gg] += r1;
                         }
                         if constexpr (EXT) {
                             if (a.elu) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[gg][e] = elu1(v[gg][e]);
+                                va[gg].x = elu1(va[gg].x); va[gg].y = elu1(va[gg].y);
+                                vb[gg].x = elu1(vb[gg].x); vb[gg].y = elu1(vb[gg].y);
                             }
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { gs1[i] += v[gg][e]; gs2[i] += v[gg][e] * v[gg][e]; }
+                            gs1v[i] += va[gg]; gs1v[i] += vb[gg];
+                            gs2v[i] = va[gg] * va[gg] + gs2v[i]; gs2v[i] = vb[gg] * vb[gg] + gs2v[i];
                         }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { s1 += v[gg][e]; s2 += v[gg][e] * v[gg][e]; }
-                        if constexpr (sizeof(TO) == 4) store4(yg + off, v[gg]);
+                        s1v += va[gg]; s1v += vb[gg];
+                        s2v = va[gg] * va[gg] + s2v; s2v = vb[gg] * vb[gg] + s2v;
+                        if constexpr (sizeof(TO) == 4) {
+                            const long long off = (((long long)(co / CBO) * a.M + m) * CBO) + (co % CBO);
+                            const float v4[4] = {va[gg].x, va[gg].y, vb[gg].x, vb[gg].y};
+                            store4(yg + off, v4);
+                        }
                     }
                 }
                 if constexpr (sizeof(TO) == 2) {
-                    uint32_t ax = pack2(v[0][0], v[0][1], TO()), ay = pack2(v[0][2], v[0][3], TO());
-                    uint32_t bx = pack2(v[1][0], v[1][1], TO()), by = pack2(v[1][2], v[1][3], TO());
+                    uint32_t ax = pack2(va[0].x, va[0].y, TO()), ay = pack2(vb[0].x, vb[0].y, TO());
+                    uint32_t bx = pack2(va[1].x, va[1].y, TO()), by = pack2(vb[1].x, vb[1].y, TO());
                     // swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second (all lanes active here)
                     const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
                     const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
@@ -110,6 +129,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16 (&a
         }
     }
 
+    ADK_TS(5)
     // halo rows of the output: zeroed by the first / last tile of each sample
     if (t == 0 || t == a.tps - 1) {
         const int plane0 = cobase / CBO;
@@ -133,7 +153,7 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16 (&a
         const int ngrp = (a.Cout_alloc + 31) >> 5;
 #pragma unroll
         for (int i = 0; i < TCO; ++i) {
-            const float r1 = wave_sum(gs1[i]), r2 = wave_sum(gs2[i]);
+            const float r1 = wave_sum(gs1v[i].x + gs1v[i].y), r2 = wave_sum(gs2v[i].x + gs2v[i].y);
             const int g = (cobase >> 5) + wco * TCO + i;
             if ((tid & 63) == 0 && g < ngrp) {
                 float* dst = a.partials + ((((long long)b * ngrp + g) * a.tps + t) * WPOS + wpos) * 2;
@@ -142,12 +162,14 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16 (&a
         }
     } else if (a.partials) {
         float* red = reinterpret_cast<float*>(smem);
+        float s1 = s1v.x + s1v.y, s2 = s2v.x + s2v.y;
         block_sum2(s1, s2, red);
         if (tid == 0) {
             float* dst = a.partials + ((long long)(b * a.tps + t) * a.ncot + cot) * 2;
             dst[0] = s1; dst[1] = s2;
         }
     }
+    ADK_TS(6)
 }
 
 // two instantiations: the residual variant keeps its raw residual pieces in registers; the plain one carries none of it
@@ -285,12 +307,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_simple_kernel(const ConvArgs
 // MFMA group:
 //   phase g:  ds_read frags(g, k-step 1) | MFMAs(g, k-step 0) | wait unit g+1 -> s_barrier -> issue unit
 //             g+K (into the slot phase g-1 released) | ds_read frags(g+1, k-step 0) | MFMAs(g, k-step 1)
-#ifdef ADK_ABL_TS
-__device__ unsigned long long g_adk_ts[16384 * 4];
-#define ADK_TS(SLOT_) if (threadIdx.x == 0 && blockIdx.x < 16384) g_adk_ts[blockIdx.x * 4 + (SLOT_)] = wall_clock64();
-#else
-#define ADK_TS(SLOT_)
-#endif
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
@@ -318,7 +334,7 @@ __global__ __launch_bounds__(WCO * WPOS * 64, (WCO * WPOS == 8 ? 1 : 2)) void co
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_adk_ts[blockIdx.x * 4 + 3] = ((unsigned long long)xcc << 32) | hwid;
+        g_adk_ts[blockIdx.x * 8 + 3] = ((unsigned long long)xcc << 32) | hwid;
     }
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -44,6 +44,32 @@ __global__ __launch_bounds__(256, (TCO * TPOS >= 4 ? 1 : 2)) void conv_ksplit_ke
     const long long xplane = a.M * 64;
     const long long wtap = (long long)a.CoutPad * 64;
 
+    // The epilogue's operands are fetched FIRST, before the K loop: wave w finishes D[co = cobase + 32 i + 8 w + 4 h + e]
+    // [pos = l0 + 32 j + l31], so its bias / residual pieces are known now, and a load issued after the first store
+    // would wait for that store's acknowledgement (loads and stores share vmcnt on gfx9; these kernels are
+    // latency-bound).  Lanes outside the tensor read a valid address of their own sample and discard it.
+    typedef typename RawVec4<TO>::type Raw4;
+    float4 bpre[TCO];
+    Raw4 rpre[TCO][TPOS];
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+        bpre[i] = a.bias ? *reinterpret_cast<const float4*>(a.bias + cobase + i * 32 + 8 * wave + 4 * (lane >> 5))
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.residual) {
+        constexpr int CBR = ElemTraits<TO>::CB;
+        const TO* rgp = reinterpret_cast<const TO*>(a.residual);
+#pragma unroll
+        for (int i = 0; i < TCO; ++i)
+#pragma unroll
+            for (int j = 0; j < TPOS; ++j) {
+                int co = cobase + i * 32 + 8 * wave + 4 * (lane >> 5);
+                co = co < a.Cout_alloc ? co : 4 * (lane >> 5);
+                const int l = l0 + j * 32 + (lane & 31);
+                const long long m = (long long)b * a.Lp + a.P + (l < a.L ? l : 0);
+                rpre[i][j] = *reinterpret_cast<const Raw4*>(rgp + ((((long long)(co / CBR) * a.M + m) * CBR) + (co % CBR)));
+            }
+    }
+
     Frag fa[DEPTH][TAPS][TCO][2], fb[DEPTH][TAPS][TPOS][2];
     f32x16 acc[TCO][TPOS];
 #pragma unroll
@@ -129,15 +155,12 @@ __global__ __launch_bounds__(256, (TCO * TPOS >= 4 ? 1 : 2)) void conv_ksplit_ke
                 const float4 p = red[((sw * S + i * TPOS + j) * 4 + wave) * 64 + lane];
                 v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
             }
-            if (a.bias) {
-                const float4 bb = *reinterpret_cast<const float4*>(a.bias + co);
-                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-            }
+            v[0] += bpre[i].x; v[1] += bpre[i].y; v[2] += bpre[i].z; v[3] += bpre[i].w;
             if (lvalid && co < a.Cout_alloc) {
                 const long long off = (((long long)(co / CBO) * a.M + m) * CBO) + (co % CBO);
                 if (rg) {
                     float rr[4];
-                    load4(rg + off, rr);
+                    raw_to_float4(rpre[i][j], rr, TO());
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += rr[e];
                 }

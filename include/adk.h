@@ -13,7 +13,7 @@
  * Activation layout ("chunk-plane", CPL) used by every kernel except the NCL boundary ops:
  *   element (b, c, l) of a [B, C, L] tensor with halo P lives at
  *       (((c / CB) * M) + b * Lp + P + l) * CB + (c % CB)        (in elements)
- *   with Lp = L + 2P, M = B * Lp, CB = 64 bytes / sizeof(elem) (16 for f32, 32 for bf16);
+ *   with Lp = L + 2P, M = B * Lp, CB = 64 bytes / sizeof(elem) (16 for f32, 32 for bf16 / f16);
  *   C is padded up to a multiple of CB (pad channels hold zeros), halo rows hold zeros
  *   (every producer kernel writes them), so k-tap convolutions read their zero padding from memory.
  */
@@ -64,7 +64,7 @@ enum {
 
 /* flags */
 #define ADK_FLAG_GELU 1u        /* GN_APPLY: apply exact (erf) GELU after the affine            */
-#define ADK_FLAG_OUT_F32 2u     /* CONV: output (and residual) tensors are f32 CPL even if dtype=bf16 */
+#define ADK_FLAG_OUT_F32 2u     /* CONV: output (and residual) tensors are f32 CPL even if dtype is 16-bit */
 #define ADK_FLAG_NOISE 4u       /* DDIM_UPDATE: add c * noise (eta > 0)                           */
 #define ADK_FLAG_ADA 8u         /* GN_APPLY: AdaGN (blocks/blocks.py:61-64): gamma/beta are per-SAMPLE rows
                                    (row stride i0 floats) and the scale is gamma + 1                */
@@ -159,7 +159,7 @@ int adk_attn1d_hd(int dtype, int B, int L, int P, int C, int head_dim, const voi
 
 /* Replaces AdaGN.forward (blocks/blocks.py:61-64) [+ nn.GELU, flag ADK_FLAG_GELU]: F.group_norm(x, groups) then
  * bias[b] + xn * (weight[b] + 1).  weight/bias f32, one row of `row_stride` floats per sample (the two halves of the
- * mapper's output, :62).  Groups must be whole channel planes (C/groups a multiple of 16 f32 / 32 bf16) or 1;
+ * mapper's output, :62).  Groups must be whole channel planes (C/groups a multiple of 16 f32 / 32 bf16, f16) or 1;
  * partials_in = adk_gn_stats of x ([B][adk_partials_count][2]).  y may alias x. */
 int adk_adagn_apply(int dtype, uint32_t flags, int B, int L, int P, int C, int groups, float eps,
                     const void *x, const float *partials_in, int n_partials_in,
@@ -233,7 +233,7 @@ int adk_step_advance(int32_t *step, void *stream);
  * (weights re-indexed on the host: audio_diffusion_amd/unet.py), with these row shuffles around it:
  *   space_to_depth: x CPL [B,C,L]     -> y CPL [B,f*C,L/f],  y[p*C + c][m] = x[c][m*f + p]
  *   depth_to_space: x CPL [B,f*C,L]   -> y CPL [B,C,L*f],    y[c][j*f + s] = x[s*C + c][j]
- * C must be a multiple of the channel chunk (16 f32 / 32 bf16); L is the INPUT length. */
+ * C must be a multiple of the channel chunk (16 f32 / 32 bf16, f16); L is the INPUT length. */
 int adk_space_to_depth(int dtype, int B, int L, int P, int C, int factor, const void *x, void *y, void *stream);
 int adk_depth_to_space(int dtype, int B, int L, int P, int C, int factor, const void *x, void *y, void *stream);
 

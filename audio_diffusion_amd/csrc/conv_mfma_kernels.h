@@ -4,7 +4,7 @@
 #pragma once
 #include "conv_common.h"
 
-#ifdef ADK_ABL_TS       // experiment builds only: per-block timestamps (tools: .exp/ts_exp.py)
+#ifdef ADK_ABL_TS       // experiment builds only: per-block timestamps (make exp-ts; tools/conv_block_timeline.py)
 __device__ unsigned long long g_adk_ts[16384 * 8];
 #define ADK_TS(SLOT_) if (threadIdx.x == 0 && blockIdx.x < 16384) g_adk_ts[blockIdx.x * 8 + (SLOT_)] = wall_clock64();
 #else
@@ -31,29 +31,16 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16 (&a
 #pragma unroll
     for (int i = 0; i < TCO; ++i) { gs1v[i] = s1v; gs2v[i] = s1v; }
     // All loads of the epilogue are issued BEFORE its first store.  On gfx9 loads and stores share one in-order
-    // counter (vmcnt), so a bias / residual load issued after a store cannot be waited for without also waiting for
-    // that store's write acknowledgement (~1 us under load): with the loads interleaved per channel group the
-    // epilogue ran as 16-32 serial round trips and took as long as the K loop of a 128-channel level
-    // (per-block timestamps: 13 us of 25).
-    float4 bb[TCO][4];
-#pragma unroll
-    for (int i = 0; i < TCO; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            bb[i][g] = a.bias ? *reinterpret_cast<const float4*>(a.bias + cobase + (wco * TCO + i) * 32 + 8 * g + 4 * h)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
-#ifdef ADK_ABL_TS
-    if (a.bias) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    // counter (vmcnt), so a load issued after a store cannot be waited for without also waiting for that store's write
+    // acknowledgement (~1 us under load): with bias / residual loads interleaved per channel group the epilogue ran as
+    // 16-32 serial round trips and took as long as the K loop of a 128-channel level (per-block timestamps: 13 us of
+    // 25).  The bias is not loaded here at all: the accumulators START at the bias (conv_acc_init, fetched while the
+    // first tiles are in flight), so acc already is conv + bias.
     ADK_TS(4)
-#endif
 #pragma unroll
     for (int j = 0; j < TPOS; ++j) {
         const int l = l0 + (wpos * TPOS + j) * 32 + l31;
-#ifdef ADK_ABL_NOSTORE
-        const bool lvalid = l < a.L && a.B < 0;
-#else
         const bool lvalid = l < a.L;
-#endif
         const long long m = (long long)b * a.Lp + a.P + l;
         // this position's residual pieces: raw loads first (one round trip), conversion at the point of use; lanes
         // outside the tensor read a valid address of their own sample and discard it
@@ -80,12 +67,8 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16 (&a
 #pragma unroll
                 for (int gg = 0; gg < 2; ++gg) {
                     const int G = g0 + gg, co = co32 + 8 * G + 4 * h;
-                    const float4 bv = bb[i][G];
                     va[gg].x = acc[i][j][4 * G]; va[gg].y = acc[i][j][4 * G + 1];
                     vb[gg].x = acc[i][j][4 * G + 2]; vb[gg].y = acc[i][j][4 * G + 3];
-                    f32x2 b0, b1;
-                    b0.x = bv.x; b0.y = bv.y; b1.x = bv.z; b1.y = bv.w;
-                    va[gg] += b0; vb[gg] += b1;
                     if (lvalid && co < a.Cout_alloc) {
                         if constexpr (RES) {
                             float rr[4];
@@ -172,6 +155,34 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16 (&a
     ADK_TS(6)
 }
 
+// Accumulators start at the bias: lane (l31, h) holds D[co = 8 g + 4 h + e][pos] in acc[..][4 g + e], so the value depends
+// on (i, g, e, h) only.  conv_bias_fetch issues the 8 float4 loads before the first LDS-DMA unit (older in the in-order
+// vmcnt queue: the counted waits of the K loop are unaffected, and the latency hides behind the first tiles' flight);
+// conv_acc_set copies them into the accumulators right after the prologue's wait, which already covers them.
+template <int TCO>
+__device__ __forceinline__ void conv_bias_fetch(const ConvArgs& a, float4 (&bv)[TCO][4], int cobase, int wco, int h)
+{
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            bv[i][g] = a.bias ? *reinterpret_cast<const float4*>(a.bias + cobase + (wco * TCO + i) * 32 + 8 * g + 4 * h)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+template <int TCO, int TPOS>
+__device__ __forceinline__ void conv_acc_set(f32x16 (&acc)[TCO][TPOS], const float4 (&bv)[TCO][4])
+{
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < TPOS; ++j) {
+                acc[i][j][4 * g] = bv[i][g].x; acc[i][j][4 * g + 1] = bv[i][g].y;
+                acc[i][j][4 * g + 2] = bv[i][g].z; acc[i][j][4 * g + 3] = bv[i][g].w;
+            }
+}
+
 // two instantiations: the residual variant keeps its raw residual pieces in registers; the plain one carries none of it
 template <bool EXT, typename TO, int BN, int BM, int WPOS, int TCO, int TPOS>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TCO][TPOS], unsigned char* smem,
@@ -255,12 +266,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_simple_kernel(const ConvArgs
     };
 
     f32x16 acc[TCO][TPOS];
-#pragma unroll
-    for (int i = 0; i < TCO; ++i)
-#pragma unroll
-        for (int j = 0; j < TPOS; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    {
+        float4 bv[TCO][4];
+        conv_bias_fetch<TCO>(a, bv, cobase, wco, h);
+        conv_acc_set<TCO, TPOS>(acc, bv);
+    }
 
     // fragment rows: weights at (tap*BN + wco*TCO*32 + i*32 + l31), activations at (wpos*TPOS*32 + j*32 + l31 + tap)
     const unsigned char* wfrag = ws + (wco * TCO * 32 + l31) * 64;
@@ -310,6 +320,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_simple_kernel(const ConvArgs
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// The same wait as an intrinsic the compiler's own waitcnt bookkeeping can see (gfx9 encoding: vmcnt in bits 3:0 and
+// 15:14, expcnt / lgkmcnt left at "no wait").  Used for the prologue wait only: it tells the compiler that the bias
+// loads issued before the first LDS-DMA unit have landed, so it does not put a vmcnt(0) - which would also drain the
+// units in flight - in front of the first MFMA that reads the bias-initialised accumulators.
+template <int N> __device__ __forceinline__ void wait_vmcnt_visible() {
+    __builtin_amdgcn_s_waitcnt((N & 0xf) | ((N >> 4) << 14) | (0x7 << 4) | (0xf << 8));
+    asm volatile("" ::: "memory");
+}
 
 template <bool EXT, typename T, typename TO, int TAPS, int WCO, int WPOS, int TCO, int TPOS, int DIL = 1>
 __global__ __launch_bounds__(WCO * WPOS * 64, (WCO * WPOS == 8 ? 1 : 2)) void conv_mfma_kernel(const ConvArgs a)
@@ -348,11 +366,7 @@ __global__ __launch_bounds__(WCO * WPOS * 64, (WCO * WPOS == 8 ? 1 : 2)) void co
     const int b = (int)(r1 / (unsigned)a.tps);
     const int cobase = cot * BN;
     const int l0 = t * BM;
-#ifdef ADK_ABL_HOTX
-    const long long mrow0 = a.P + (long long)(lid & 7u) * BM - (EXT ? a.shift : TAPS / 2);
-#else
     const long long mrow0 = (long long)b * a.Lp + a.P + l0 - (EXT ? a.shift : TAPS / 2);   // EXT: causal / dilated taps
-#endif
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -364,6 +378,10 @@ __global__ __launch_bounds__(WCO * WPOS * 64, (WCO * WPOS == 8 ? 1 : 2)) void co
     const long long xplane = a.M * 64;
     const long long wchunk = (long long)TAPS * a.CoutPad * 64;
     const int total = a.nchunks * TAPS;
+
+    f32x16 acc[TCO][TPOS];
+    float4 bv[TCO][4];
+    conv_bias_fetch<TCO>(a, bv, cobase, wco, h);           // bias loads go out first (see conv_bias_fetch)
 
     // per-lane source offsets (bytes) inside a plane / a weight chunk, fixed for the whole kernel
     unsigned xsrc[XI], wsrc[WI];
@@ -394,14 +412,6 @@ __global__ __launch_bounds__(WCO * WPOS * 64, (WCO * WPOS == 8 ? 1 : 2)) void co
         for (int j = 0; j < WI; ++j) glds16(wb + wsrc[j], dst + j * (NW * 1024));
     };
 
-    f32x16 acc[TCO][TPOS];
-#pragma unroll
-    for (int i = 0; i < TCO; ++i)
-#pragma unroll
-        for (int j = 0; j < TPOS; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     const int wfrag = (wco * TCO * 32 + l31) * 64;
     const int xfrag = (wpos * TPOS * 32 + l31) * 64;
     const int wsw = (l31 >> 2) & 3;
@@ -426,7 +436,8 @@ __global__ __launch_bounds__(WCO * WPOS * 64, (WCO * WPOS == 8 ? 1 : 2)) void co
         if (u < total) issue_unit(u);
     {
         constexpr int n0 = []() { int n = 0; for (int u = 1; u < K; ++u) n += WI + (u % TAPS == 0 ? XI : 0); return n; }();
-        if (total >= K) wait_vmcnt<n0>(); else wait_vmcnt<0>();
+        if (total >= K) { wait_vmcnt_visible<n0>(); conv_acc_set<TCO, TPOS>(acc, bv); }
+        else { wait_vmcnt_visible<0>(); conv_acc_set<TCO, TPOS>(acc, bv); }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         ADK_LOAD_FRAGS(a0, b0, ws + wfrag, xs + xfrag, wsw, 0)

@@ -52,6 +52,24 @@ __global__ __launch_bounds__(256) void gn_kernel(const GnArgs a)
     const int rb = blockIdx.x, plane = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x, q = tid & 3, r0 = tid >> 2;
 
+    const long long rowbase = (long long)plane * a.M + (long long)b * a.Lp;
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x) + rowbase * 64 + q * 16;
+    const unsigned char* rbp = RES ? reinterpret_cast<const unsigned char*>(a.residual) + rowbase * 64 + q * 16 : nullptr;
+    unsigned char* yb = APPLY ? reinterpret_cast<unsigned char*>(a.y) + rowbase * 64 + q * 16 : nullptr;
+
+    const int lbeg = rb * a.RB, lend = (lbeg + a.RB < a.L) ? lbeg + a.RB : a.L;
+    // this thread's first piece is requested before the statistics are finalized (two barriers and a dependent load of
+    // the partials): at the short levels, where a thread owns one or two rows, that takes one memory round trip out of
+    // a launch that is nothing but latency
+    int l = lbeg + r0;
+    const bool pre = l < lend && a.RB <= 256;      // long levels keep their 4-deep batches intact
+    uint4 px = make_uint4(0, 0, 0, 0), pr = make_uint4(0, 0, 0, 0);
+    if (pre) {
+        const long long ro = (long long)(a.P + l) * 64;
+        px = *reinterpret_cast<const uint4*>(xb + ro);
+        if (RES) pr = *reinterpret_cast<const uint4*>(rbp + ro);
+    }
+
     float scale[NV], shift[NV];
     if (APPLY) {
         float mean, rstd;
@@ -67,12 +85,6 @@ __global__ __launch_bounds__(256) void gn_kernel(const GnArgs a)
             shift[e] = real ? bt[c0 + e] - mean * scale[e] : 0.f;
         }
     }
-    const long long rowbase = (long long)plane * a.M + (long long)b * a.Lp;
-    const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x) + rowbase * 64 + q * 16;
-    const unsigned char* rbp = RES ? reinterpret_cast<const unsigned char*>(a.residual) + rowbase * 64 + q * 16 : nullptr;
-    unsigned char* yb = APPLY ? reinterpret_cast<unsigned char*>(a.y) + rowbase * 64 + q * 16 : nullptr;
-
-    const int lbeg = rb * a.RB, lend = (lbeg + a.RB < a.L) ? lbeg + a.RB : a.L;
     float s1 = 0.f, s2 = 0.f;
     auto body = [&](const uint4& xin, const uint4& rin, long long ro) {
         if constexpr (sizeof(T) == 2) {              // bf16 / f16: pairs, packed-f32 arithmetic
@@ -119,7 +131,7 @@ __global__ __launch_bounds__(256) void gn_kernel(const GnArgs a)
         }
     };
     constexpr int U = 4;                             // independent 16-byte loads in flight per thread
-    int l = lbeg + r0;
+    if (pre) { body(px, pr, (long long)(a.P + l) * 64); l += 64; }
     for (; l + 64 * (U - 1) < lend; l += 64 * U) {
         uint4 xin[U], rin[U];
 #pragma unroll

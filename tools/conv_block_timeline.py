@@ -37,14 +37,14 @@ def run(cin, L, B=16):
     ts = buf.reshape(-1, 8)[:n]
     t0 = ts[:, 0].min()
     start, kend, end = [(ts[:, i] - t0).astype(np.float64) / 100.0 for i in range(3)]   # us (100 MHz)
-    tb, tst, tsum = [(ts[:, i] - t0).astype(np.float64) / 100.0 for i in (4, 5, 6)]
-    print(f"  epilogue split: bias wait {np.mean(tb - kend):.2f}  compute+store issue {np.mean(tst - tb):.2f}  halo+block_sum {np.mean(tsum - tst):.2f}  drain {np.mean(end - tsum):.2f} us")
     hw = ts[:, 3]
     xcc = (hw >> np.uint64(32)).astype(np.int64); hwid = (hw & np.uint64(0xffffffff)).astype(np.int64)
     cu = (hwid >> 8) & 0xf; se = (hwid >> 13) & 0x7; sh = (hwid >> 12) & 1
     cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
     print(f"C={cin} L={L}: {nblk} blocks, total {end.max():.1f} us; distinct CUs {len(set(cuid.tolist()))}")
     print(f"  per block: K-loop {np.mean(kend - start):.2f} us (p10 {np.percentile(kend-start,10):.2f}, p90 {np.percentile(kend-start,90):.2f}), epilogue+drain {np.mean(end - kend):.2f} us (p10 {np.percentile(end-kend,10):.2f}, p90 {np.percentile(end-kend,90):.2f})")
+    tb, tst, tsum = [(ts[:, i] - t0).astype(np.float64) / 100.0 for i in (4, 5, 6)]
+    print(f"  epilogue split: bias wait {np.mean(tb - kend):.2f}  compute+store issue {np.mean(tst - tb):.2f}  halo+block_sum {np.mean(tsum - tst):.2f}  drain {np.mean(end - tsum):.2f} us")
     # per CU: fraction of time with 0/1/2 blocks in K-loop
     tot = np.zeros(3); T = end.max()
     for c in list(set(cuid.tolist()))[:64]:

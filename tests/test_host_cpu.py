@@ -70,7 +70,7 @@ def test_full_model_init_matches_reference_digest():
 
 @pytest.mark.parametrize("name", ["tiny_d3.npz", "tiny_d5.npz", "tiny_d3_pqmf4.npz", "tiny_d4_noattn_nobias.npz",
                                   "tiny_learned_k7.npz", "tiny_learned_s3_k3.npz", "tiny_d3_k7_fir.npz", "tiny_d3_cond.npz"])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_tiny_models_load_and_plan(name, dtype):
     z = load_npz(name)
     cfg = json.loads(bytes(z["cfg"]).decode())

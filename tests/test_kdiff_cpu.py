@@ -34,7 +34,7 @@ def test_oracle_matches_reference_goldens(name):
 
 
 @pytest.mark.parametrize("name", CASES)
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_ctor_parity_and_plan(name, dtype):
     z = load_npz(name)
     cfg, extra, x, sigma = unpack(z)

@@ -26,7 +26,7 @@ def test_oracle_matches_reference_goldens(name):
 
 
 @pytest.mark.parametrize("name", CASES)
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_ctor_parity_and_plan(name, dtype):
     z = load_npz(name)
     cfg = json.loads(bytes(z["cfg"]).decode())
@@ -75,7 +75,7 @@ def test_encoder_oracle_ctor_and_plan(name):
     for k in sd:
         assert torch.equal(sd[k], ref_sd[k]), k
     B, _, T = z["x"].shape
-    for dtype in (torch.float32, torch.bfloat16):
+    for dtype in (torch.float32, torch.bfloat16, torch.float16):
         plan = _SSPlan(m, B, T, dtype, torch.device("cpu"))
         plan.validate()
         kinds = [plan.ops[i].kind for i in range(plan.n_ops)]

@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--T", type=int, default=65536)
-    ap.add_argument("--model", default="uncond", help="uncond (config 2) | k-audio (k_audio_uncond_long_1.json, B=4, 32 x 32768)")
+    ap.add_argument("--model", default="uncond", help="uncond (config 2) | 3a (long context) | k-audio (k_audio_uncond_long_1.json, B=4, 32 x 32768)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "fp32": torch.float32}[a.dtype]
@@ -39,7 +39,11 @@ def main():
         out = torch.empty_like(x)
         plan.bind_named(input=x.data_ptr(), t=t.data_ptr(), output=out.data_ptr())
     else:
-        m = A.DiffusionAttnUnet1D(n_attn_layers=4).to(dev).eval()
+        if a.model == "3a":                       # BASELINE config 3a: default ctor (attention up to s = 4096), B = 4 x 2^18
+            a.batch, a.T = (4 if a.batch == 16 else a.batch), (262144 if a.T == 65536 else a.T)
+            m = A.DiffusionAttnUnet1D().to(dev).eval()
+        else:
+            m = A.DiffusionAttnUnet1D(n_attn_layers=4).to(dev).eval()
         plan = m.plan_for(a.batch, a.T, dtype, dev)
         x = torch.randn(a.batch, 2, a.T, device=dev)
         t = torch.ones(a.batch, device=dev)

@@ -167,7 +167,7 @@ template <> struct AttMma<f16_t> {
 };
 
 template <typename T, int TQ, int DP>         // DP = 64-byte planes per head (head dim 32 * DP)
-__global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnMfmaArgs a)
+__global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnMfmaArgs a)   // 2 blocks / CU: <= 256 registers, so the MFMAs take VGPR operands (no v_accvgpr copies around the softmax)
 {
     typedef typename AttMma<T>::Frag Frag;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -298,7 +298,11 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const AttnMfmaArgs a)
             for (int s = 0; s < 2; ++s) {
                 union { uint32_t w[4]; Frag f; } pk;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pk.w[e] = pack2(st[8 * s + 2 * e], st[8 * s + 2 * e + 1], T());
+                for (int e = 0; e < 4; ++e) {            // one conversion instruction per pair (pack2v): the softmax
+                    f32x2 pv;                              // tile is VALU-bound, the two-cast form costs 4 per pair
+                    pv.x = st[8 * s + 2 * e]; pv.y = st[8 * s + 2 * e + 1];
+                    pk.w[e] = pack2v(pv, T());
+                }
                 pf[s] = pk.f;
             }
 #pragma unroll

@@ -285,14 +285,21 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnMfmaArgs a)
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float mnew = fmaxf(mrun[u], mx * c);
             const float alpha = __builtin_amdgcn_exp2f(mrun[u] - mnew);
+            const bool rescale = __ballot(mnew != mrun[u]) != 0ull;   // alpha == 1 exactly on every lane otherwise
             mrun[u] = mnew;
-            float psum = 0.f;
+            // pairs: one v_pk_fma_f32 and one v_pk_add_f32 per two scores (the exp2 itself is not packable)
+            f32x2 ps2 = {0.f, 0.f};
+            const f32x2 c2 = {c, c}, m2 = {-mnew, -mnew};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                st[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c, -mnew));
-                psum += st[r];
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 t2;
+                t2.x = st[r]; t2.y = st[r + 1];
+                t2 = t2 * c2 + m2;
+                t2.x = __builtin_amdgcn_exp2f(t2.x); t2.y = __builtin_amdgcn_exp2f(t2.y);
+                st[r] = t2.x; st[r + 1] = t2.y;
+                ps2 += t2;
             }
-            lrun[u] = lrun[u] * alpha + psum;
+            lrun[u] = lrun[u] * alpha + (ps2.x + ps2.y);
             Frag pf[2];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -307,8 +314,10 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnMfmaArgs a)
             }
 #pragma unroll
             for (int p = 0; p < DP; ++p) {
+                if (rescale) {                            // wave-uniform: skipped once the running maxima have settled
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[u][p][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) o[u][p][r] *= alpha;
+                }
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
                     o[u][p] = AttMma<T>::run(vf[p][s], pf[s], o[u][p]);

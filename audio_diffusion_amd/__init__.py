@@ -17,7 +17,7 @@ from .sampling import (sample, sample_crash, sample_diffae, audio_to_int16, get_
                        sample_lms, to_d)
 from .pqmf import CachedPQMF
 from .kdiffusion import AudioDenoiserModel, Denoiser
-from . import _lib, blocks
+from . import _lib, blocks, distributed
 
 __all__ = ["DiffusionAttnUnet1D", "sample", "sample_crash", "sample_diffae", "audio_to_int16", "get_alphas_sigmas",
            "alpha_sigma_to_t", "get_crash_schedule", "step_coefficients", "CachedPQMF", "AudioDenoiserModel", "Denoiser", "get_sigmas_karras", "get_sigmas_exponential", "sample_heun", "sample_lms", "to_d"]

@@ -60,7 +60,7 @@ EXPORTS = [
     "adk_pack_input", "adk_pack_input_cond", "adk_unpack_output", "adk_pqmf_analysis", "adk_pqmf_synthesis",
     "adk_ddim_update", "adk_step_advance", "adk_audio_to_int16", "adk_space_to_depth", "adk_depth_to_space",
     "adk_attn1d_hd", "adk_adagn_apply", "adk_linear", "adk_fourier_features", "adk_pack_input_plain",
-    "adk_unpack_output_scaled",
+    "adk_unpack_output_scaled", "adk_group_norm_noalloc",
 ]
 
 _lib = None
@@ -113,6 +113,7 @@ def load():
     lib.adk_fourier_features.argtypes = [u32, i32, i32, vp, vp, vp, i32, vp]
     lib.adk_pack_input_plain.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp, vp]
     lib.adk_unpack_output_scaled.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.adk_group_norm_noalloc.argtypes = [i32, u32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         if name not in ("adk_last_error",):
             getattr(lib, name).restype = C.c_int

@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 #include "adk_common.h"
 
 int launch_conv(const adk_op& op, hipStream_t st);
@@ -25,6 +26,17 @@ int launch_linear(const adk_op& op, hipStream_t st);
 int launch_fourier(const adk_op& op, hipStream_t st);
 
 static thread_local char g_err[512] = "";
+
+// ---- scratch of the allocation-free entry point (adk_group_norm_noalloc, bottom of this file) ----------------------
+// GroupNorm statistics partials, (sum, sumsq) pairs: [B][adk_partials_count] of ONE call.  Every GPU the library runs
+// on holds its own copy of this array at its own address until the process ends (4 MiB).  In host code the array's
+// NAME is only a handle for hipGetSymbolAddress: the per-device address it returns (g_scratch_ptr) is what kernels,
+// memsets and copies get.
+#define ADK_NOALLOC_MAX_PAIRS (512 * 1024)
+static __device__ __align__(256) float scratch[ADK_NOALLOC_MAX_PAIRS * 2];
+#define ADK_MAX_DEVICES 64
+static float* g_scratch_ptr[ADK_MAX_DEVICES];        // per device, filled on the entry point's first call there
+static std::mutex g_scratch_mutex;
 
 static int fail(int code, const char* fmt, ...)
 {
@@ -442,6 +454,59 @@ int adk_step_advance(int32_t* step, void* stream)
     adk_op o = zero_op(ADK_OP_STEP_ADVANCE, ADK_F32);
     o.y = step;
     return adk_run_plan(&o, 1, stream);
+}
+
+// Address of this device's copy of `scratch` (looked up once per device, with that device current).
+static int scratch_for_current_device(hipStream_t st, float** out)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ADK_MAX_DEVICES)
+        return fail(ADK_ELAUNCH, "group_norm_noalloc: no current HIP device (or its index is >= %d)", ADK_MAX_DEVICES);
+    if (st) {                                    // the scratch copy used must be the one of the device that runs the kernels
+        hipDevice_t sdev;
+        if (hipStreamGetDevice(st, &sdev) == hipSuccess && (int)sdev != dev)
+            return fail(ADK_EINVAL, "group_norm_noalloc: the stream belongs to device %d but device %d is current", (int)sdev, dev);
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        float* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr)
+            return fail(ADK_ELAUNCH, "group_norm_noalloc: hipGetSymbolAddress(scratch) failed on device %d: %s", dev,
+                        hipGetErrorString(e));
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return ADK_OK;
+}
+
+int adk_group_norm_noalloc(int dtype, uint32_t flags, int B, int L, int P, int C, float eps,
+                           const void* x, const float* gamma, const float* beta, const void* residual, void* y,
+                           void* stream)
+{
+    adk_op s = zero_op(ADK_OP_GN_STATS, dtype);
+    s.B = B; s.L = L; s.P = P; s.Cin = C; s.x = x;
+    s.partials_out = reinterpret_cast<float*>(1);        // placeholder for validation; patched below
+    int rc = validate(s);
+    if (rc) return rc;
+    const int n = gn_partials_count(dtype, C, L);
+    if ((long long)B * n > ADK_NOALLOC_MAX_PAIRS)
+        return fail(ADK_EINVAL, "group_norm_noalloc: B * partials = %d * %d pairs exceed the built-in scratch of %d pairs "
+                    "(use adk_gn_stats + adk_gn_apply with a caller-owned buffer)", B, n, ADK_NOALLOC_MAX_PAIRS);
+    adk_op o = zero_op(ADK_OP_GN_APPLY, dtype);
+    o.flags = flags & ADK_FLAG_GELU; o.B = B; o.L = L; o.P = P; o.Cin = C; o.Cout = C; o.f0 = eps;
+    o.x = x; o.n_partials_in = n; o.gamma = gamma; o.beta = beta; o.residual = residual; o.y = y;
+    o.partials_in = reinterpret_cast<const float*>(1);
+    if ((rc = validate(o))) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    float* ptr = nullptr;
+    if ((rc = scratch_for_current_device(st, &ptr))) return rc;
+    s.partials_out = ptr;                        // the device address, never the array's name
+    o.partials_in = ptr;
+    // nothing has to start at zero: the statistics kernel overwrites all B * n pairs the apply kernel reads
+    if ((rc = dispatch(s, st)) || (rc = dispatch(o, st)))
+        return fail(rc, "group_norm_noalloc: launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return ADK_OK;
 }
 
 }  // extern "C"

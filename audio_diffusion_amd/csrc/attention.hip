@@ -5,10 +5,11 @@
 // Layout: qkv is CPL [B, 3C, L] with channel order (q heads | k heads | v heads); a head's d channels
 // are d/32 64-byte rows (bf16) or d/16 (f32) in consecutive planes, so Q/K/V tiles of a head are row ranges.
 //
-// bf16: attn_mfma_kernel.  One WAVE owns TQ*32 query rows of one (sample, head) and streams that head's
-// K/V in 32-key tiles through a wave-private LDS ring filled by LDS-DMA (3 tiles in flight, counted vmcnt,
-// no block barrier anywhere).  Everything is kept "query on the lane":
-//     S^T = K Q^T          v_mfma_f32_32x32x16_bf16, A = K rows (ds_read_b128, source-swizzled image),
+// bf16 / f16: attn_mfma_kernel.  One WAVE owns TQ*32 query rows of one (sample, head) and streams that head's
+// K/V in 32-key tiles: K rows go global -> registers directly in A-fragment layout, V rows global -> registers ->
+// a wave-private LDS double buffer (tile kt+1 is in flight while kt computes; no block barrier anywhere).
+// Everything is kept "query on the lane":
+//     S^T = K Q^T          v_mfma_f32_32x32x16_{bf16,f16}, A = K rows (registers, straight from global),
 //                          B = Q rows (registers, loaded once);  lane (q, h) gets 16 of the 32 keys
 //     online softmax       fp32, exp2 with the d^-1/2 scale folded into the exponent; the row max / sum
 //                          need ONE cross-half exchange per tile

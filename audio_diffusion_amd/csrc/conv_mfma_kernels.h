@@ -338,8 +338,11 @@ __global__ __launch_bounds__(WCO * WPOS * 64, (WCO * WPOS == 8 ? 1 : 2)) void co
 #ifndef ADK_CONV_K      // prefetch depth in units; -DADK_CONV_K=2 / 3 builds measured within 1 % of 4 on every level
 #define ADK_CONV_K 4
 #endif
-    constexpr int K = TAPS >= 3 ? ADK_CONV_K : 2;         // unit g+K is issued during phase g
+    // unit g+K is issued during phase g.  K <= TAPS whenever X is double-buffered: X(kc+1) then goes out during chunk kc
+    // (never X(kc+2) into the buffer chunk kc's last tap is still reading fragments from)
+    constexpr int K = TAPS >= 3 ? (ADK_CONV_K < TAPS ? ADK_CONV_K : TAPS) : 2;
     constexpr int RW = K + 1, RX = TAPS == 1 ? K + 1 : 2;
+    static_assert(RX > 2 || K <= TAPS, "prefetch depth must not reach past the X double buffer");
     constexpr int XROWS = BM + (TAPS - 1) * DIL;
     constexpr int XI = (XROWS + 16 * NW - 1) / (16 * NW);    // X LDS-DMA instructions per wave (uniform; tile padded)
     constexpr int WI = BN / (16 * NW);                        // W LDS-DMA instructions per wave per unit
@@ -494,7 +497,7 @@ static int launch_variant(const adk_op& op, hipStream_t st)
     ConvArgs a;
     conv_fill_args(op, BN, BM, a);
     if constexpr (BN >= 128) {
-        constexpr int K = TAPS >= 3 ? ADK_CONV_K : 2;
+        constexpr int K = TAPS >= 3 ? (ADK_CONV_K < TAPS ? ADK_CONV_K : TAPS) : 2;
         constexpr int NW = WCO * WPOS;
         constexpr int XI = (BM + (TAPS - 1) * DIL + 16 * NW - 1) / (16 * NW);
         const size_t lds = (size_t)(TAPS == 1 ? K + 1 : 2) * XI * NW * 1024 + (size_t)(K + 1) * BN * 64;

@@ -50,6 +50,8 @@ def all_gather_audio(local):
     """[b_r, C, T] per rank -> [sum b_r, C, T] on every rank (rank order).  Equal shards use one
     all_gather_into_tensor (a single ring pass over xGMI); ragged shards pad to the largest."""
     world = dist.get_world_size()
+    if dist.get_backend() != "nccl" and local.is_cuda:      # gloo rehearsal on a GPU box: gather through host memory
+        return all_gather_audio(local.cpu()).to(local.device)
     sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
     mine = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     dist.all_gather(sizes, mine)
@@ -69,10 +71,9 @@ def all_gather_audio(local):
 @torch.no_grad()
 def sample_sharded(model, noise, steps, eta, sampler):
     """Every rank passes the SAME global `noise` [B,C,T] (generated once from one seed); each rank runs
-    its contiguous shard through `sampler(model, x, steps, eta)` and the full batch is all-gathered."""
-    rank, world = dist.get_rank(), dist.get_world_size()
-    lo, hi = shard_bounds(noise.shape[0], rank, world)
-    return all_gather_audio(sampler(model, noise[lo:hi], steps, eta))
+    its contiguous shard through `sampler(model, x, steps, eta)` and the full batch is all-gathered.  A rank whose
+    shard is empty (more ranks than samples) never calls the sampler (it rejects B = 0, like the reference's convs)."""
+    return run_sharded(lambda x: sampler(model, x, steps, eta), noise)
 
 
 @torch.no_grad()

@@ -1,27 +1,35 @@
 #!/usr/bin/env python3
 """Headline benchmark: audio-seconds generated per second, 2^16-sample stereo, 100-step v-DDIM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|f16|fp32] [--batch 16] [--ddim-steps 100]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f16|bf16|fp32] [--batch B] [--global-batch G]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is ONE pass of the hot path over one batch: ``sample(model, x[B,2,65536], 100, eta=0)`` on the
-221M-parameter uncond DiffusionAttnUnet1D (BASELINE.json configs[1]; random-init weights seed 0, noise
-seed 1, synthetic).  Multi-GPU is batch-parallel (weak scaling: B per GPU fixed), one process per GPU,
-with one RCCL all-gather of the output audio inside the timed region.  Rank 0 prints ONE JSON line.
+221M-parameter uncond DiffusionAttnUnet1D (random-init weights seed 0, noise seed 1, synthetic).
 
-Extra objects in the line:
+* N = 1: BASELINE.json configs[1] (batch 16 on one MI355X).
+* N > 1: BASELINE.json configs[4]: a GLOBAL batch of 256 split N ways (128 / 64 / 32 per GPU, strong scaling), one
+  process per GPU, noise generated ONCE from a single CPU seed and sliced per rank, no collective in the step loop,
+  one RCCL all-gather of the output audio INSIDE the timed region.  ``--batch B`` switches to B samples per GPU.
+* ``python bench.py --gpus N`` without a launcher starts the N ranks itself (a child ``torch.distributed.run``),
+  BEFORE this process has touched the GPU (no exec after HIP initialisation anywhere).
+
+Rank 0 prints ONE JSON line.  Extra objects in it:
   roofline     : the dominant kernel (k=5 implicit-GEMM conv on MFMA), algorithmic FLOPs / HIP-event time,
                  measured live on the launch stream after the timed region (same plan, same buffers).
+  accuracy     : first denoiser call of the timed dtype against one fp32 call of this build on the same x
+                 (scale-relative max error max|a-b|/max|b| and relative L2), N = 1 only.
+  fp32 / bf16  : ONE timed pass each of the same workload in the other dtypes of configs[1], N = 1 only.
   cpu_baseline : the repo's CPU oracle (plain PyTorch fp32, oracle/) timed on the host cores on a bounded
                  sample (B=1, a few denoiser calls), extrapolated to the 100-step metric.  Reported only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -29,18 +37,67 @@ sys.path.insert(0, ROOT)
 SAMPLE_RATE = 48000          # reference defaults.ini:41
 T = 65536                    # reference defaults.ini:23
 PEAK = {"bf16": 2500.0, "f16": 2500.0, "fp32": 157.3}     # dense MFMA TFLOP/s (MI355X_MICROARCH.md)
-DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16, "fp32": torch.float32}
+FLOP_PER_CALL_PER_SAMPLE = 6.899e11
+ERR_METRIC = "scale-relative max error max|a-b|/max|b| of one denoiser call"
+
+
+def dtypes():
+    import torch
+    return {"bf16": torch.bfloat16, "f16": torch.float16, "fp32": torch.float32}
 
 
 def build_model():
+    import torch
     import audio_diffusion_amd as A
     torch.manual_seed(0)
     return A.DiffusionAttnUnet1D(n_attn_layers=4).eval()
 
 
-def cpu_baseline(model, calls, threads):
+def host_cpu_budget():
+    """Threads for the CPU baseline: all PHYSICAL cores this process may use.  The GPU box shows the whole machine
+    in os.cpu_count(); the job's share is bounded by the scheduler affinity and the cgroup CPU quota (both read
+    here) and by the OMP_NUM_THREADS the box exports for a one-GPU lease."""
+    logical = os.cpu_count() or 1
+    cores, sib = set(), {}
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+        if core is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    physical = len(cores) or logical
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = logical
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(p)))
+    except (OSError, ValueError):
+        pass
+    omp = os.environ.get("OMP_NUM_THREADS")
+    omp = int(omp) if omp and omp.isdigit() else None
+    share = min(x for x in (physical, affinity, quota, omp) if x)
+    return {"threads": share, "host_logical": logical, "host_physical": physical, "affinity": affinity,
+            "cgroup_quota": quota, "omp_num_threads": omp}
+
+
+def cpu_baseline(model, calls, budget):
     """Time the CPU oracle (test infrastructure; never on the product path) on config 1's shape."""
+    import torch
     from oracle import unet_oracle as U, sampling_oracle as S
+    threads = budget["threads"]
     torch.set_num_threads(threads)
     cfg = U.make_config(n_attn_layers=4)
     fn = U.make_model_fn(model.state_dict(), cfg)
@@ -53,12 +110,16 @@ def cpu_baseline(model, calls, threads):
         fn(x, torch.ones(1) * t[i])
     dt = (time.perf_counter() - t0) / calls
     return {"value": (T / SAMPLE_RATE) / (dt * 100), "unit": "audio-s/s", "cores": threads, "kind": "port",
+            "host": {k: v for k, v in budget.items() if k != "threads"},
+            "cores_note": "threads = min(physical cores, scheduler affinity, cgroup CPU quota, the box's OMP_NUM_THREADS): "
+                          "the physical cores this job may actually use; host_logical / host_physical describe the whole machine",
             "sample": f"B=1 x 2x{T}, {calls} denoiser calls timed ({dt:.3f} s/call), x100 for the 100-step loop; "
                       "the DDIM update itself is <0.1% of a call"}
 
 
 def conv_roofline(model, B, dtype, dev, reps=3):
     """HIP-event timing of every k=5 MFMA conv launch of one denoiser call, on the launch stream."""
+    import torch
     from audio_diffusion_amd import _lib
     plan = model.plan_for(B, T, dtype, dev)
     x = torch.randn(B, 2, T, device=dev)
@@ -87,7 +148,7 @@ def conv_roofline(model, B, dtype, dev, reps=3):
         if r:                                        # first pass is a warm-up
             for i, (e0, e1) in evs.items():
                 ms[i] += e0.elapsed_time(e1) / reps
-    key = {v: k for k, v in DTYPES.items()}[dtype]
+    key = {v: k for k, v in dtypes().items()}[dtype]
     per = {}
     for pt, idx in groups.items():
         fl = sum(plan.meta[i]["flops"] for i in idx)
@@ -103,7 +164,7 @@ def conv_roofline(model, B, dtype, dev, reps=3):
             "separate --pmc passes, profiles/)", "algorithmic_bytes_per_launch": alg_bytes,
             "launches_per_call": d["launches_per_call"], "avg_launch_us": d["avg_launch_us"],
             "flop_per_launch_avg": d["flop_per_call"] / d["launches_per_call"],
-            "share_of_call_flop": d["flop_per_call"] / (6.899e11 * B),
+            "share_of_call_flop": d["flop_per_call"] / (FLOP_PER_CALL_PER_SAMPLE * B),
             "other_tiles": {str(k): {"tflops": v["tflops"], "launches_per_call": v["launches_per_call"],
                                      "avg_launch_us": v["avg_launch_us"]} for k, v in per.items() if k != dom}}
 
@@ -111,16 +172,17 @@ def conv_roofline(model, B, dtype, dev, reps=3):
 def pmc_traffic(key, tile):
     """HBM bytes per launch of the dominant kernel from the committed counter summary (tools/run_pmc.sh ->
     profiles/rNN/pmc_summary.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction).
-    bench.py cannot collect counters itself; null when no summary covers this kernel."""
+    bench.py cannot collect counters itself; null when no summary covers this kernel and dtype."""
     import glob
     import re
     m = re.match(r"(\d+)co x (\d+)pos", tile)
-    if not m or key != "bf16":
+    if not m or key not in ("bf16", "f16"):
         return None
     tpos = int(m.group(2)) // 64
-    # conv_mfma_kernel<EXT=false, bf16, bf16, TAPS=5, WCO=2, WPOS=2, TCO=2, TPOS, DIL=1> (older summaries: no EXT / DIL)
-    pat = re.compile(rf"_Z16conv_mfma_kernelI(Lb0E)?DF16bDF16bLi5ELi2ELi2ELi2ELi{tpos}E(Li1E)?Ev8ConvArgs$")
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.json")), reverse=True):
+    el = "DF16b" if key == "bf16" else "DF16_"
+    # conv_mfma_kernel<EXT=false, T, TO, TAPS=5, WCO=2, WPOS=2, TCO=2, TPOS, DIL=1> (older summaries: no EXT / DIL)
+    pat = re.compile(rf"_Z16conv_mfma_kernelI(Lb0E)?{el}{el}Li5ELi2ELi2ELi2ELi{tpos}E(Li1E)?Ev8ConvArgs$")
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary*.json")), reverse=True):
         try:
             summary = json.load(open(f))
         except (OSError, ValueError):
@@ -137,82 +199,204 @@ def _offset(ops, i):
     return ctypes.cast(ctypes.byref(ops, i * ctypes.sizeof(_lib.AdkOp)), ctypes.POINTER(_lib.AdkOp))
 
 
+def first_call_accuracy(model, x, dtype, dev):
+    """The timed dtype's first denoiser call (t = 1, what step 0 of the loop computes) against ONE fp32 call of this
+    build on the same x; per-sample work, so two samples stand for the batch."""
+    import torch
+    xs = x[:2].contiguous()
+    tt = torch.ones(xs.shape[0], device=dev)
+    prev = model.compute_dtype
+    try:
+        model.compute_dtype = torch.float32
+        ref = model(xs, tt).double()
+        model.compute_dtype = dtype
+        got = model(xs, tt).double()
+    finally:
+        model.compute_dtype = prev
+    return {"metric": ERR_METRIC, "reference": "this build's fp32 path (held to <= 1e-4 of the reference by tests/test_gpu_model.py)",
+            "max_rel": float((got - ref).abs().max() / ref.abs().max()),
+            "rel_l2": float((got - ref).norm() / ref.norm()), "samples": int(xs.shape[0]),
+            "bound": 1e-2 if dtype != torch.float32 else 1e-4}
+
+
+def timed_pass(model, x, dtype, ddim_steps, dev):
+    """ONE timed pass of the workload in another dtype (plan build, graph capture and one untimed pass first)."""
+    import torch
+    import audio_diffusion_amd as A
+    prev = model.compute_dtype
+    try:
+        model.compute_dtype = dtype
+        A.sample(model, x, ddim_steps, 0)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        out = A.sample(model, x, ddim_steps, 0)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        assert torch.isfinite(out).all()
+        acc = first_call_accuracy(model, x, dtype, dev) if dtype != torch.float32 else None
+    finally:
+        model.compute_dtype = prev
+        for k in [k for k in model._plans if dtype in k]:         # release this dtype's arena
+            del model._plans[k]
+        torch.cuda.empty_cache()
+    B = x.shape[0]
+    rec = {"value": B * T / SAMPLE_RATE / dt, "unit": "audio-s/s", "passes": 1, "ms_per_step": dt * 1e3,
+           "ms_per_denoiser_call": dt * 1e3 / ddim_steps,
+           "model_tflops": FLOP_PER_CALL_PER_SAMPLE * B * ddim_steps / dt / 1e12}
+    if acc:
+        rec["accuracy"] = acc
+    return rec
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(a, argv):
+    """``python bench.py --gpus N`` with no launcher around it: start the N ranks as ONE child process
+    (torch.distributed.run, rendezvous on 127.0.0.1, a free port) and pass its exit code on.  This process has made no
+    HIP call and never will: it only waits."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "fp32"])
-    ap.add_argument("--batch", type=int, default=16, help="samples per GPU")
+    ap.add_argument("--dtype", default="f16", choices=["bf16", "f16", "fp32"],
+                    help="f16 = the reference's own autocast dtype (diffusion/sampling.py:30)")
+    ap.add_argument("--batch", type=int, default=0, help="samples per GPU (default: 16 at N=1, global batch / N otherwise)")
+    ap.add_argument("--global-batch", type=int, default=256, help="configs[4]: total samples over all GPUs when N > 1")
     ap.add_argument("--ddim-steps", type=int, default=100)
     ap.add_argument("--cpu-calls", type=int, default=4, help="denoiser calls timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the accuracy object and the fp32 / bf16 sub-records")
+    ap.add_argument("--backend", default=None, help="nccl (= RCCL, default on GPUs) or gloo (CPU rehearsal of the launcher)")
+    ap.add_argument("--standin", action="store_true",
+                    help="CPU rehearsal: a stand-in per-sample function replaces the HIP sampler (launcher, sharding, "
+                         "all-gather and the JSON line are the real ones); never a measurement")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
-    import audio_diffusion_amd as A
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+
+    import torch
     from audio_diffusion_amd import distributed as D
-
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+    DT = dtypes()
+    dtype = DT[a.dtype]
+    if a.standin:
+        dev = torch.device("cpu")
+    else:
+        ndev = torch.cuda.device_count()
+        dev = torch.device("cuda", local % max(ndev, 1))
+        torch.cuda.set_device(dev)
     if world > 1:
-        D.init(rank, world)
-    dtype = DTYPES[a.dtype]
+        D.init(rank, world, backend=a.backend or ("gloo" if a.standin else "nccl"))
 
-    model = build_model()
-    cpu = None
-    if rank == 0 and world == 1 and a.cpu_calls > 0:
-        cpu = cpu_baseline(model, a.cpu_calls, min(16, os.cpu_count() or 1))
-    model = model.to(dev)
-    model.compute_dtype = dtype
+    # workload: configs[1] at N = 1, configs[4] (global batch split N ways) at N > 1, --batch B = B per GPU
+    if a.batch:
+        total, scaling = a.batch * world, "weak"
+    elif world == 1:
+        total, scaling = 16, "weak"
+    else:
+        total, scaling = a.global_batch, "strong"
+    lo, hi = D.shard_bounds(total, rank, world)
+
+    if a.standin:
+        model, cpu = None, None
+
+        def sampler(m, xx, steps, eta):
+            return torch.tanh(xx * 3.0) + steps
+    else:
+        import audio_diffusion_amd as A
+        model = build_model()
+        cpu = None
+        if rank == 0 and world == 1 and a.cpu_calls > 0:
+            cpu = cpu_baseline(model, a.cpu_calls, host_cpu_budget())
+        model = model.to(dev)
+        model.compute_dtype = dtype
+        sampler = A.sample
 
     # noise generated ONCE from a single CPU seed and sliced per rank: a sample's result does not depend on N
     g = torch.Generator().manual_seed(1)
-    noise = torch.randn(a.batch * world, 2, T, generator=g)
-    x = noise[rank * a.batch:(rank + 1) * a.batch].to(dev)
+    Tn = 64 if a.standin else T
+    noise = torch.randn(total, 2, Tn, generator=g)
+    x = noise[lo:hi].to(dev)
+    del noise
 
     def one_pass():
-        pred = A.sample(model, x, a.ddim_steps, 0)
+        pred = sampler(model, x, a.ddim_steps, 0)
         return D.all_gather_audio(pred) if world > 1 else pred
+
+    def sync():
+        if not a.standin:
+            torch.cuda.synchronize(dev)
 
     for _ in range(a.warmup):
         one_pass()
     D.barrier(world)
-    torch.cuda.synchronize(dev)
+    sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = one_pass()
     D.barrier(world)
-    torch.cuda.synchronize(dev)
+    sync()
     dt = time.perf_counter() - t0
     dt = D.max_over_ranks(dt, world, dev)
-    assert torch.isfinite(out).all()
+    assert out.shape[0] == total and torch.isfinite(out).all()
 
     if rank == 0:
+        import torch.distributed as dist
         ms = dt / a.steps * 1e3
-        total_audio_s = world * a.batch * T / SAMPLE_RATE
+        per_gpu = hi - lo
         rec = {
             "metric": "audio-seconds generated/sec, 2^16-sample stereo, 100-step v-DDIM",
-            "value": total_audio_s / (ms * 1e-3), "unit": "audio-s/s",
+            "value": total * Tn / SAMPLE_RATE / (ms * 1e-3), "unit": "audio-s/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"configs[1]: DiffusionAttnUnet1D uncond (221M params, random init seed 0), "
-                                   f"batch {a.batch}/GPU x 2ch x {T}, {a.ddim_steps}-step v-DDIM eta=0, "
-                                   "hipGraph-captured step loop",
-                       "batch_per_gpu": a.batch, "global_batch": a.batch * world, "ddim_steps": a.ddim_steps,
-                       "parallelism": f"batch-parallel x{world}" + (" + RCCL all-gather of output" if world > 1 else "")},
+            "config": {"workload": (f"configs[1]: DiffusionAttnUnet1D uncond (221M params, random init seed 0), batch {total} x 2ch x {T}"
+                                    if world == 1 else
+                                    f"configs[4]: the same model, global batch {total} x 2ch x {T} sharded over {world} GPUs "
+                                    f"({per_gpu} per GPU), RCCL all-gather of the output audio inside the timed region")
+                       + f", {a.ddim_steps}-step v-DDIM eta=0, hipGraph-captured step loop",
+                       "batch_per_gpu": per_gpu, "global_batch": total, "ddim_steps": a.ddim_steps,
+                       "parallelism": f"batch-parallel x{world}" + (" + all-gather of output" if world > 1 else "")},
             "ms_per_denoiser_call": ms / a.ddim_steps,
-            "model_tflops": 6.899e11 * a.batch * world * a.ddim_steps / (ms * 1e-3) / 1e12,        # whole job
+            "model_tflops": FLOP_PER_CALL_PER_SAMPLE * total * a.ddim_steps / (ms * 1e-3) / 1e12,        # whole job
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "backend": dist.get_backend() if world > 1 else None,
         }
-        if not a.no_roofline:
-            rec["roofline"] = conv_roofline(model, a.batch, dtype, dev)
-        if cpu is not None:
-            rec["cpu_baseline"] = cpu
+        if a.standin:
+            rec["data"] = "STAND-IN sampler on CPU (launcher rehearsal, not a measurement)"
+        else:
+            if not a.no_roofline:
+                rec["roofline"] = conv_roofline(model, per_gpu, dtype, dev)
+            if world == 1 and not a.no_extra:
+                rec["accuracy"] = first_call_accuracy(model, x, dtype, dev)
+                for k in [k for k in list(model._plans)]:             # free the timed dtype's arenas before the others
+                    del model._plans[k]
+                torch.cuda.empty_cache()
+                for other in ("fp32", "bf16", "f16"):
+                    if other != a.dtype and (other == "fp32" or a.dtype == "f16"):
+                        rec[other] = timed_pass(model, x, DT[other], a.ddim_steps, dev)
+            if cpu is not None:
+                rec["cpu_baseline"] = cpu
         print(json.dumps(rec), flush=True)
     D.barrier(world)
     if world > 1:

@@ -242,6 +242,18 @@ int adk_depth_to_space(int dtype, int B, int L, int P, int C, int factor, const 
  * x f32 [B, C, T] -> y int16 [C, B*T] (truncation toward zero, like torch's float -> int16 cast). */
 int adk_audio_to_int16(int B, int C, int T, const float *x, int16_t *y, void *stream);
 
+/* nn.GroupNorm(1, C)(x) [-> nn.GELU() with ADK_FLAG_GELU] [+ residual] in ONE call that allocates nothing and takes no
+ * workspace: the variant of adk_gn_stats + adk_gn_apply for callers that cannot call hipMalloc (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid allocation).  It has NO counterpart in the reference (which
+ * allocates freely through PyTorch).  The (sum, sumsq) partials that adk_gn_apply takes as the workspace argument
+ * `partials_in` live in a fixed 4 MiB array inside the library (one copy per GPU, held until the process ends):
+ * B * adk_partials_count(GN op) must be <= 524288 pairs, else ADK_EINVAL (e.g. B=16, C=128, L=65536 needs 4096).
+ * Output bits equal adk_gn_stats + adk_gn_apply.  Calls that overlap in time on ONE GPU (two streams) share that
+ * array and race; calls on one stream, or on different GPUs, do not.  The stream's device must be current. */
+int adk_group_norm_noalloc(int dtype, uint32_t flags, int B, int L, int P, int C, float eps,
+                           const void *x, const float *gamma, const float *beta, const void *residual, void *y,
+                           void *stream);
+
 #ifdef __cplusplus
 }
 #endif

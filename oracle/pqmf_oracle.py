@@ -110,3 +110,35 @@ def synthesis(x, inverse_w, bands):
     y = F.conv1d(F.pad(y, (half, half)), inverse_w) * bands
     y = y.flip(1).permute(0, 2, 1).reshape(c * b, 1, n * bands)    # interleave phases
     return y.reshape(c, b, n * bands).permute(1, 0, 2).contiguous()
+
+
+# ---- base (non-cached) PQMF paths, pqmf.py:95-233: CPU cross-check of the cached bank ----------------
+def base_forward(x, hk, polyphase=True):
+    """PQMF.forward, pqmf.py:212-222 (x [B,1,T], hk [M,K] with K a power of two): polyphase_forward :95-110 or
+    classic_forward :140-157, then reverse_half."""
+    m, k = hk.shape
+    if polyphase:
+        b, c, t = x.shape
+        xp = x.reshape(b, c, t // m, m).permute(0, 1, 3, 2).reshape(b, c * m, t // m)       # "b c (t m) -> b (c m) t"
+        w = hk.reshape(m, k // m, m).permute(0, 2, 1)                                          # "c (t m) -> c m t"
+        y = F.conv1d(xp, w, padding=w.shape[-1] // 2)[..., :-1]
+    else:
+        y = F.conv1d(x, hk.unsqueeze(1), stride=m, padding=k // 2)[..., :-1]
+    return flip_alternate(y)
+
+
+def base_inverse(y, hk, polyphase=True):
+    """PQMF.inverse, pqmf.py:224-233: reverse_half, then polyphase_inverse :113-137 or classic_inverse :160-179."""
+    m, k = hk.shape
+    y = flip_alternate(y)
+    if polyphase:
+        w = hk.flip(-1).reshape(m, k // m, m).permute(2, 0, 1)                                # "c (t m) -> m c t"
+        pad = w.shape[-1] // 2 + 1
+        z = F.conv1d(y, w, padding=pad)[..., :-1] * m
+        z = z.flip(1)
+        b, cm, t = z.shape
+        z = z.reshape(b, cm // m, m, t).permute(0, 1, 3, 2).reshape(b, cm // m, t * m)         # "b (c m) t -> b c (t m)"
+        return z[..., 2 * w.shape[1]:]
+    up = torch.zeros(*y.shape[:2], m * y.shape[-1]).to(y)
+    up[..., ::m] = y * m
+    return F.conv1d(up, hk.flip(-1).unsqueeze(0), padding=k // 2)[..., 1:]

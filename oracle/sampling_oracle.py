@@ -12,8 +12,8 @@ import torch
 
 def crash_schedule(t):
     """train_uncond.py:35-38 (get_crash_schedule): sigma = sin(t pi/2)^2, alpha = sqrt(1 - sigma^2), back to t.
-    That script cannot be imported here (prefigure / wandb / aeiou are absent), so this three-line warp is pinned
-    only by restating its formula: parity unpinned for the warp itself; the loop around it is the pinned one."""
+    Pinned by tests/golden/glue.npz (crash/*): tools/make_goldens.py compiles just that script's function definitions
+    (ast; the script itself needs prefigure / wandb / aeiou and is never imported) and records their outputs."""
     sigma = torch.sin(t * math.pi / 2) ** 2
     alpha = (1 - sigma ** 2) ** 0.5
     return alpha_sigma_to_t(alpha, sigma)
@@ -53,3 +53,11 @@ def ddim_sample(model, x, steps, eta, trace=None, crash=False, **extra):
             if eta:
                 x = x + torch.randn_like(x) * ddim_sigma
     return pred
+
+
+@torch.no_grad()
+def diffae_sample(model, signal, steps, eta, noise):
+    """diffusion/inference.py:14-57: z_sem = model.encode(signal) once, start from ``noise`` (the reference draws
+    randn_like(signal) at :26; passed in here so a fixture can pin it), then the loop of :29-54 on model.decode."""
+    z_sem = model.encode(signal)
+    return ddim_sample(lambda x, t: model.decode(x, t, z_sem), noise, steps, eta)

@@ -20,6 +20,8 @@ def _free_port():
 
 
 def _fake_sampler(model, x, steps, eta):
+    if x.shape[0] == 0:                          # like the real sampler (check_geo: "bad geometry B=0")
+        raise ValueError("empty batch")
     return torch.tanh(x * 3.0) + steps          # any per-sample function
 
 
@@ -46,19 +48,43 @@ def _worker(rank, world, port, total, q):
 def test_sharded_sampling_world2(total):
     world = 2
     ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
+    q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out, mx = q.get()
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    try:
+        out, mx = q.get(timeout=120)            # a failing worker must not hang the suite
+    finally:
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
     g = torch.Generator().manual_seed(1)
     noise = torch.randn(total, 2, 64, generator=g)
     assert torch.equal(out, _fake_sampler(None, noise, 5, 0))       # same as the 1-rank result, rank order kept
     assert mx == 2.0
+
+
+def test_bench_launcher_world2_gloo():
+    """`python bench.py --gpus 2` exactly as the driver calls it (no launcher around it): the parent starts the two
+    ranks itself, they rendezvous on 127.0.0.1 (gloo here, RCCL on GPUs), shard configs[4]'s global batch, all-gather
+    inside the timed region, and rank 0 prints ONE JSON line.  --standin replaces only the HIP sampler."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--standin", "--global-batch", "7"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["backend"] == "gloo"
+    assert rec["scaling"] == "strong" and rec["config"]["global_batch"] == 7 and rec["config"]["batch_per_gpu"] == 4
+    assert rec["steps"] == 2 and rec["warmup"] == 1 and rec["value"] > 0
 
 
 def test_shard_bounds_cover_everything():

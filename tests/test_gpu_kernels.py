@@ -356,6 +356,23 @@ def test_pqmf_vs_golden(env, golden_pqmf, ch, att, M):
     assert rel_err(r, torch.from_numpy(z[f"{tag}/z"])) <= 1e-5
 
 
+@pytest.mark.parametrize("M", [4, 16])
+def test_pqmf_vs_reference_base_class(env, M):
+    """the product's CachedPQMF (libadk kernels) against outputs of the reference's base-class PQMF
+    (polyphase path, diffusion/pqmf.py:95-137, 212-233 - no cached_conv involved; tests/golden/glue.npz):
+    forward equal, inverse equal after its M-sample delay."""
+    from conftest import load_npz
+    from audio_diffusion_amd import CachedPQMF
+    lib, _lib, layout, dev = env
+    g = load_npz("glue.npz")
+    x, y, z = (torch.from_numpy(g[f"pqmf_base_m{M}_poly/{n}"]) for n in ("x", "y", "z"))
+    q = CachedPQMF(1, 70, M).to(dev)
+    assert rel_err(q.hk, torch.from_numpy(g[f"pqmf_base_m{M}_poly/hk"])) <= 1e-6
+    assert rel_err(q(x.to(dev)), y) <= 1e-5
+    back = q.inverse(y.to(dev)).cpu()
+    assert rel_err(back[..., M:], z[..., :-M]) <= 1e-5
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 def test_pack_unpack(env, golden_blocks, dt):
     lib, _lib, layout, dev = env

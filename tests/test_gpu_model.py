@@ -3,17 +3,17 @@
 Bars (north_star): per-denoiser-call output within rtol 1e-4 in fp32 (scale-relative max error,
 conftest.rel_err) and final eta=0 audio at SNR >= 60 dB in fp32.
 
-bf16: north_star asks 1e-2.  Rounding ONLY the MFMA inputs (weights + conv inputs) to bf16 in the CPU
-oracle already gives 1.2-1.3e-2 max / 0.5-1.0e-2 relative-L2 error on these random-init models
-("bf16 error floor"), so the bar the bf16 path is held to here is: relative L2 error <= 2e-2 and
-scale-relative max error <= 5e-2 on the tiny (C = 32..96) models, <= 2e-2 max on the full 221M model.
+Reduced precision: north_star asks 1e-2.  f16 (the reference's own autocast dtype, diffusion/sampling.py:30, and
+the dtype bench.py headlines) is held to exactly that.  bf16 cannot be: rounding ONLY the MFMA operands to bf16 in
+the CPU oracle already costs 1.0-1.9e-2 (tests/test_dtype_floor_cpu.py derives it), so every bf16 bar below is
+max(1e-2, 3 x that floor computed in the test for the same model and input) - never a bare constant.
 """
 import json
 
 import pytest
 import torch
 
-from conftest import load_npz, sub_sd, rel_err, snr_db
+from conftest import load_npz, sub_sd, rel_err, snr_db, rounding_floor
 
 pytestmark = pytest.mark.gpu
 
@@ -52,10 +52,12 @@ def test_tiny_forward_bf16(name):
     m.compute_dtype = torch.bfloat16
     y = m(torch.from_numpy(z["x"]).to(dev), torch.from_numpy(z["t"]).to(dev))
     ref = torch.from_numpy(z["y"])
-    assert rel_err(y, ref) <= 5e-2
-    # learned-resampler models round two more bf16 tensors per level (phase-folded conv output) and, at C = 32..64
-    # with k = 3, average over short dot products: 2.6e-2 measured on tiny_learned_s3_k3 (fp32 path: <= 1e-4)
-    assert float((y.cpu().double() - ref.double()).norm() / ref.double().norm()) <= (3e-2 if "learned" in name else 2e-2)
+    cfg = json.loads(bytes(z["cfg"]).decode())
+    fmax, fl2 = rounding_floor(sub_sd(z, "sd/"), cfg, torch.from_numpy(z["x"]), torch.from_numpy(z["t"]), torch.bfloat16)
+    l2 = float((y.cpu().double() - ref.double()).norm() / ref.double().norm())
+    print(f"{name}: bf16 max-rel {rel_err(y, ref):.2e} (operand-rounding floor {fmax:.2e}), L2 {l2:.2e} (floor {fl2:.2e})")
+    assert rel_err(y, ref) <= max(1e-2, 3 * fmax)
+    assert l2 <= max(1e-2, 3 * fl2)
 
 
 @pytest.mark.parametrize("name", TINY)
@@ -145,32 +147,39 @@ def test_full_model_first_call_and_10_steps():
     pred = A.sample(m, x, 10, 0)
     ref = torch.from_numpy(z["pred"])
     assert snr_db(pred, ref) >= 60.0
-    m.compute_dtype = torch.bfloat16
-    v0b = m(x, torch.ones(1, device=dev))
-    assert rel_err(v0b, ref_v0) <= 2e-2
-    m.compute_dtype = torch.float16                      # the reference's autocast dtype: within the north_star's 1e-2
+    m.compute_dtype = torch.float16                      # the reference's autocast dtype and bench.py's headline dtype
     v0h = m(x, torch.ones(1, device=dev))
-    assert rel_err(v0h, ref_v0) <= 5e-3                  # measured 1.9e-3 (bf16: 1.6e-2)
+    l2h = float((v0h.cpu().double() - ref_v0.double()).norm() / ref_v0.double().norm())
+    assert rel_err(v0h, ref_v0) <= 5e-3 and l2h <= 5e-3  # north_star: 1e-2; measured 1.9e-3
     predh = A.sample(m, x, 10, 0)
     assert torch.isfinite(predh).all() and snr_db(predh, ref) >= 60.0      # measured 79 dB: the fp32 bar, in half
+    # bf16: bar derived from the operand-rounding floor of THIS model and input (CPU oracle, two calls)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    fmax, fl2 = rounding_floor(sd, dict(n_attn_layers=4), x.cpu(), torch.ones(1), torch.bfloat16)
+    m.compute_dtype = torch.bfloat16
+    v0b = m(x, torch.ones(1, device=dev))
+    l2b = float((v0b.cpu().double() - ref_v0.double()).norm() / ref_v0.double().norm())
+    predb = A.sample(m, x, 10, 0)
+    print(f"full model bf16: max-rel {rel_err(v0b, ref_v0):.2e} (floor {fmax:.2e}), L2 {l2b:.2e} (floor {fl2:.2e}), "
+          f"10-step SNR {snr_db(predb, ref):.1f} dB; f16: {rel_err(v0h, ref_v0):.2e}, {snr_db(predh, ref):.1f} dB")
+    assert rel_err(v0b, ref_v0) <= max(1e-2, 3 * fmax) and l2b <= max(1e-2, 3 * fl2)
+    assert snr_db(predb, ref) >= 50.0                    # measured 61 dB; 60 dB is the fp32 bar
 
 
 def test_crash_schedule_sampler_and_int16_output_stage():
-    """the training demos' sampler (train_uncond.py:45-86: crash-warped timesteps) against the oracle
-    loop on the same warp, and the int16 output stage (train_uncond.py:182-187) bit-exact against torch."""
+    """the training demos' sampler (train_uncond.py:45-86: crash-warped timesteps) against the output of
+    the reference's own function definitions (tests/golden/glue.npz, tools/make_goldens.py tier G), and the int16
+    output stage (train_uncond.py:182-187) bit-exact against torch."""
     import audio_diffusion_amd as A
-    from oracle import unet_oracle as U, sampling_oracle as S
     dev = torch.device("cuda:0")
-    z = load_npz("tiny_d3.npz")
-    m = build(z, dev)
+    z, g = load_npz("tiny_d3.npz"), load_npz("glue.npz")
+    m = build(z, dev)                                        # glue.npz was recorded on this very model (seed 0)
     m.compute_dtype = torch.float32
-    cfg = json.loads(bytes(z["cfg"]).decode())
-    ref_model = U.make_model_fn(sub_sd(z, "sd/"), U.make_config(**cfg))
-    x = torch.from_numpy(z["x"])
-    want = S.ddim_sample(ref_model, x, 6, 0, crash=True)
+    x = torch.from_numpy(g["crash/x"])
+    want = torch.from_numpy(g["crash/pred6"])
     got = A.sample_crash(m, x.to(dev), 6, 0)
     assert rel_err(got, want) <= 1e-4 and snr_db(got, want) >= 60.0
-    assert not torch.allclose(got.cpu(), S.ddim_sample(ref_model, x, 6, 0), atol=1e-3)      # the warp matters
+    assert not torch.allclose(got, A.sample(m, x.to(dev), 6, 0), atol=1e-3)      # the warp matters
 
     fakes = torch.randn(3, 2, 1001, device=dev) * 0.8                                   # odd length: scalar tail
     fakes[0, 0, :4] = torch.tensor([1.5, -1.5, 1.0, -1.0], device=dev)
@@ -181,12 +190,13 @@ def test_crash_schedule_sampler_and_int16_output_stage():
     assert torch.equal(A.audio_to_int16(big).cpu(), big.cpu().permute(1, 0, 2).reshape(2, -1).clamp(-1, 1).mul(32767).to(torch.int16))
 
 
-def test_diffae_sampler_variant():
-    """diffusion/inference.py:14-57: encode once, start from fresh noise, decode(x, t, z_sem) per step."""
+def test_diffae_sampler_variant(monkeypatch):
+    """diffusion/inference.py:14-57: encode once, start from fresh noise, decode(x, t, z_sem) per step - against the
+    output of the reference's own sample() on a toy encode/decode object (glue.npz).  The reference's start noise is
+    a CPU randn_like under seed 11; the fixture carries that draw and the test feeds it through randn_like."""
     import audio_diffusion_amd as A
-    from oracle import sampling_oracle as S
     dev = torch.device("cuda:0")
-    z = load_npz("tiny_d3.npz")
+    z, g = load_npz("tiny_d3.npz"), load_npz("glue.npz")
     m = build(z, dev)
     m.compute_dtype = torch.float32
 
@@ -197,14 +207,19 @@ def test_diffae_sampler_variant():
         def decode(self, x, t, z_sem):
             return m(x + 0.1 * z_sem, t)
 
-    sig = torch.from_numpy(z["x"]).to(dev)
-    torch.manual_seed(11)
+    sig = torch.from_numpy(g["diffae/signal"]).to(dev)
+    noise = torch.from_numpy(g["diffae/noise"]).to(dev)
+    calls = []
+
+    def fixed_randn_like(t, *a, **k):
+        calls.append(tuple(t.shape))
+        return noise.clone()
+    monkeypatch.setattr(torch, "randn_like", fixed_randn_like)
     got = A.sample_diffae(DiffAE(), sig, 4, 0)
-    torch.manual_seed(11)
-    x0 = torch.randn_like(sig)
-    zs = sig.mean(dim=2, keepdim=True)
-    want = A.sample(lambda xx, tt: m(xx + 0.1 * zs, tt), x0, 4, 0)
-    assert torch.equal(got, want) and torch.isfinite(got).all()
+    monkeypatch.undo()
+    assert calls == [tuple(sig.shape)]                       # exactly the one draw of inference.py:26 (eta = 0)
+    want = torch.from_numpy(g["diffae/pred4"])
+    assert rel_err(got, want) <= 1e-4 and snr_db(got, want) >= 60.0
 
 
 @pytest.mark.parametrize("name", ["tiny_d3_cond.npz", "tiny_d3_cond_samelen.npz", "tiny_d3_cond_aug0.npz"])
@@ -227,7 +242,12 @@ def test_conditioning_path_vs_reference_golden(name):
     m.compute_dtype = torch.bfloat16
     yb = m(x, t, **extra).cpu()
     ref = torch.from_numpy(z["y"])
-    assert float((yb - ref).norm() / ref.norm()) <= 2e-2
+    cfg = json.loads(bytes(z["cfg"]).decode())
+    cpu_extra = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in extra.items()}
+    floor = rounding_floor(sub_sd(z, "sd/"), cfg, x.cpu(), t.cpu(), torch.bfloat16, **cpu_extra)
+    assert float((yb - ref).norm() / ref.norm()) <= max(1e-2, 3 * floor[1])
+    m.compute_dtype = torch.float16
+    assert rel_err(m(x, t, **extra), ref) <= 1e-2                  # north_star's bound in the headline dtype
     with pytest.raises(RuntimeError):
         m(x, t)                                            # cond missing: the reference fails on the channel count
     with pytest.raises(RuntimeError):

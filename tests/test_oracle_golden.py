@@ -140,3 +140,68 @@ def test_conditioning_path(name):
         extra["cond_aug_scale"] = float(z["aug_scale"])
     assert rel_err(model(x, t, **extra), torch.from_numpy(z["y"])) <= 5e-6   # host-CPU dependent, as above
     assert rel_err(S.ddim_sample(model, x, int(z["steps"]), 0, **extra), torch.from_numpy(z["pred"])) <= 1e-5
+
+
+# ---- fixtures of tools/make_goldens.py tier G -----------------------------------------------------
+def _tiny_d3_oracle():
+    import json
+    from oracle import unet_oracle as U
+    z = load_npz("tiny_d3.npz")
+    sd = sub_sd(z, "sd/")
+    g = load_npz("glue.npz")
+    assert torch.equal(sd["net.0.main.0.weight"][:2, :2], torch.from_numpy(g["model_sd_check"]))    # same model
+    return U.make_model_fn(sd, U.make_config(**json.loads(bytes(z["cfg"]).decode()))), g
+
+
+def test_crash_schedule_vs_reference_fixture():
+    """train_uncond.py:35-38, outputs recorded from the reference's own function definitions."""
+    import audio_diffusion_amd as A
+    from oracle import sampling_oracle as S
+    g = load_npz("glue.npz")
+    for steps in (5, 6, 10, 100, 250):
+        want = torch.from_numpy(g[f"crash/t{steps}"])
+        t = torch.linspace(1, 0, steps + 1)[:-1]
+        assert torch.equal(S.crash_schedule(t), want)
+        assert torch.equal(A.get_crash_schedule(t), want)                      # the product's host function
+        assert torch.equal(A.step_coefficients(steps, 0, A.get_crash_schedule)[:, 0], want)
+
+
+def test_crash_sampler_and_diffae_oracle_vs_reference_fixture():
+    """The reference's train_uncond.py sample() (crash-warped DDIM) and diffusion/inference.py sample() (encode once,
+    decode per step) on the tiny_d3 model, against the oracle's restatements."""
+    from oracle import sampling_oracle as S
+    model, g = _tiny_d3_oracle()
+    x = torch.from_numpy(g["crash/x"])
+    assert rel_err(S.ddim_sample(model, x, 6, 0, crash=True), torch.from_numpy(g["crash/pred6"])) <= 1e-5
+
+    class Toy:
+        def encode(self, signal):
+            return signal.mean(dim=2, keepdim=True)
+
+        def decode(self, xx, tt, z_sem):
+            return model(xx + 0.1 * z_sem, tt)
+
+    got = S.diffae_sample(Toy(), torch.from_numpy(g["diffae/signal"]), 4, 0, torch.from_numpy(g["diffae/noise"]))
+    assert rel_err(got, torch.from_numpy(g["diffae/pred4"])) <= 1e-5
+
+
+@pytest.mark.parametrize("M", [4, 16])
+def test_base_pqmf_paths_and_cached_bank_cross_check(M):
+    """pqmf.py:95-233 (PQMF, polyphase_* / classic_*): the oracle's restatements against the reference's outputs, and
+    the cached bank the denoiser uses against them: CachedPQMF.forward == PQMF.forward exactly, CachedPQMF.inverse ==
+    PQMF.inverse delayed by M samples exactly.  Neither base path touches cached_conv, so this pins the cached bank's
+    sample values everywhere except the first M output samples of the inverse."""
+    from oracle import pqmf_oracle as Q
+    g = load_npz("glue.npz")
+    d = Q.design(70, M)
+    for tag in ("poly", "classic"):
+        k = f"pqmf_base_m{M}_{tag}"
+        x, y, z, hk = (torch.from_numpy(g[f"{k}/{n}"]) for n in ("x", "y", "z", "hk"))
+        assert rel_err(d["hk"], hk) <= 1e-6
+        assert rel_err(Q.base_forward(x, hk, tag == "poly"), y) <= 1e-6
+        assert rel_err(Q.base_inverse(y, hk, tag == "poly"), z) <= 1e-6
+    x, y, z = (torch.from_numpy(g[f"pqmf_base_m{M}_poly/{n}"]) for n in ("x", "y", "z"))
+    assert rel_err(Q.analysis(x, d["forward_w"], M), y) <= 1e-6
+    zc = Q.synthesis(y, d["inverse_w"], M)
+    assert rel_err(zc[..., M:], z[..., :-M]) <= 1e-6
+    assert rel_err(torch.from_numpy(g[f"pqmf_base_m{M}_classic/z"]), z) <= 1e-5          # the two base paths agree

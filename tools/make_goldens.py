@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate golden vectors by IMPORTING the reference (this container only).
 
-Run:  python tools/make_goldens.py [--tier B T C R K S F] [--ref /root/reference]
+Run:  python tools/make_goldens.py [--tier B T C R K S G F] [--ref /root/reference]
 Writes small fixtures (inputs + expected outputs, never source text) to tests/golden/.
 
 The reference's hot path is Python; three of its imports are unavailable or have drifted in this
@@ -378,10 +378,75 @@ def tier_full(Model, sampling):
     npz("full_seed0_steps10.npz", pred=pred, v0=vs[0])
 
 
+def extract_functions(path, names):
+    """Compile just the named top-level function definitions of a reference script (ast; the script itself is never
+    imported or run: train_uncond.py needs prefigure / wandb / aeiou, absent here) into a fresh namespace."""
+    import ast
+    import math
+    tree = ast.parse(open(path).read(), filename=path)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert sorted(n.name for n in keep) == sorted(names), [n.name for n in keep]
+    ns = {"torch": torch, "math": math, "trange": range}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def tier_glue(P, Model, ref):
+    """SURVEY 8 f3 + a16: the training demos' crash-warped sampler (train_uncond.py:35-86), the diffusion-autoencoder
+    DDIM (diffusion/inference.py:14-57) and the base (non-cached) PQMF paths (diffusion/pqmf.py:95-233)."""
+    import contextlib
+    import io
+    import warnings
+    print("tier G: crash schedule, diff-AE DDIM, base PQMF")
+    out = {}
+    ns = extract_functions(os.path.join(ref, "train_uncond.py"),
+                           ["get_alphas_sigmas", "get_crash_schedule", "alpha_sigma_to_t", "sample"])
+    for steps in (5, 6, 10, 100, 250):
+        out[f"crash/t{steps}"] = ns["get_crash_schedule"](torch.linspace(1, 0, steps + 1)[:-1])
+    # the same tiny model as tiny_d3.npz (seed 0), so no second copy of its weights is stored
+    kwargs = dict(depth=3, c_mults=[32, 32, 64], n_attn_layers=1)
+    torch.manual_seed(0)
+    m = Model(**kwargs).eval()
+    torch.manual_seed(1)
+    x = torch.randn(2, 2, 1024)
+    with warnings.catch_warnings(), contextlib.redirect_stdout(io.StringIO()):
+        warnings.simplefilter("ignore")
+        out["crash/x"] = x
+        out["crash/pred6"] = ns["sample"](m, x, 6, 0)
+
+        from diffusion import inference as INF
+
+        class ToyDiffAE:                      # any object with encode / decode (inference.py:23,33)
+            def encode(self, signal):
+                return signal.mean(dim=2, keepdim=True)
+
+            def decode(self, xx, tt, z_sem):
+                return m(xx + 0.1 * z_sem, tt)
+
+        torch.manual_seed(11)
+        noise = torch.randn_like(x)            # the draw inference.py:26 makes under this seed
+        torch.manual_seed(11)
+        out["diffae/signal"], out["diffae/noise"] = x, noise
+        out["diffae/pred4"] = INF.sample(ToyDiffAE(), x, 4, 0)
+    out["model_sd_check"] = m.state_dict()["net.0.main.0.weight"][:2, :2]
+
+    for M in (4, 16):
+        torch.manual_seed(7)
+        xb = torch.randn(2, 1, M * 96)
+        for poly in (True, False):
+            q = P.PQMF(70, M, polyphase=poly).eval()
+            tag = f"pqmf_base_m{M}_{'poly' if poly else 'classic'}"
+            with torch.no_grad():
+                y = q(xb)
+                z = q.inverse(y)
+            out.update({f"{tag}/x": xb, f"{tag}/y": y, f"{tag}/z": z, f"{tag}/hk": q.hk})
+    npz("glue.npz", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
-    ap.add_argument("--tier", nargs="+", default=["B", "T", "C", "R", "K", "S", "F"])
+    ap.add_argument("--tier", nargs="+", default=["B", "T", "C", "R", "K", "S", "G", "F"])
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     P, Model, sampling, blocks = import_reference(a.ref)
@@ -397,6 +462,8 @@ def main():
         tier_kdiff()
     if "S" in a.tier:
         tier_soundstream()
+    if "G" in a.tier:
+        tier_glue(P, Model, a.ref)
     if "F" in a.tier:
         tier_full(Model, sampling)
 

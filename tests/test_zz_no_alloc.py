@@ -20,7 +20,7 @@ def sp():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def run_case(lib, _lib, layout, dev, dt, B, Cc, L, gelu, res, seed):
+def run_case(lib, _lib, layout, dev, dt, B, Cc, L, gelu, res, seed, check_mem=True):
     dtype, adk, tol = DT[dt]
     P = 2
     g = torch.Generator().manual_seed(seed)
@@ -49,7 +49,8 @@ def run_case(lib, _lib, layout, dev, dt, B, Cc, L, gelu, res, seed):
                                     rd.data_ptr() if res else None, got.data_ptr(), sp())
     assert rc == 0, lib.adk_last_error()
     torch.cuda.synchronize()
-    assert torch.cuda.mem_get_info(dev)[0] >= free_before        # no device memory was taken by the call
+    if check_mem:                                                # (the first call on a device is the set-up: the
+        assert torch.cuda.mem_get_info(dev)[0] >= free_before    # runtime then loads the code object that holds the array)
     assert torch.equal(got, want), "no-alloc GroupNorm differs from adk_gn_stats + adk_gn_apply"
     xq = x.to(dtype).float()
     ref = F.group_norm(xq, 1, gamma, beta, 1e-5)
@@ -69,7 +70,9 @@ def test_no_alloc_group_norm_two_calls_in_a_row(dt):
     lib = _lib.load()
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    # first call: the larger input (many partials); second: a smaller one that reuses the front of the same array
+    run_case(lib, _lib, layout, dev, dt, B=1, Cc=32, L=64, gelu=False, res=False, seed=0, check_mem=False)   # set-up call
+    # then: the larger input (many partials), and smaller ones that reuse the front of the same array; none of these
+    # calls may take device memory
     run_case(lib, _lib, layout, dev, dt, B=3, Cc=128, L=20000, gelu=True, res=True, seed=1)
     run_case(lib, _lib, layout, dev, dt, B=2, Cc=96, L=300, gelu=False, res=False, seed=2)
     run_case(lib, _lib, layout, dev, dt, B=1, Cc=32, L=8, gelu=True, res=False, seed=3)

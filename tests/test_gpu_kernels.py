@@ -332,6 +332,29 @@ def test_attention_core(env, dt, B, heads, s):
     assert float(full[:, :, :P].abs().max()) == 0.0 and float(full[:, :, P + s:].abs().max()) == 0.0, "halo rows not zero"
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_attention_bits_reproducible(env, dt):
+    """The MFMA attention kernel packs its probabilities with the one-instruction conversion right after packed-f32
+    row sums of the same registers - the instruction mix that made the conv epilogue's (sum, sumsq) partials differ
+    from run to run.  Config 3a's largest launch (B=4, 16 heads, s=4096): repeated launches must give
+    identical bits."""
+    lib, _lib, layout, dev = env
+    dtype, adk, _ = DT[dt]
+    B, Cc, s, P = 4, 512, 4096, 2
+    cb = layout.chunk(dtype)
+    g = torch.Generator().manual_seed(11)
+    qkv = torch.randn(B, 3 * Cc, s, generator=g) * 1.3
+    qd = layout.to_cpl(qkv.to(dev), dtype, P)
+    outs = []
+    for _ in range(6):
+        yd = torch.full((Cc // cb, B, s + 2 * P, cb), 5.0, dtype=dtype, device=dev)
+        assert lib.adk_attn1d(adk, B, s, P, Cc, qd.data_ptr(), yd.data_ptr(), sp()) == 0, lib.adk_last_error()
+        outs.append(yd)
+    torch.cuda.synchronize()
+    for y in outs[1:]:
+        assert torch.equal(y.view(torch.int16), outs[0].view(torch.int16))
+
+
 PQMF_CASES = [(1, 70, 32), (2, 70, 32), (2, 70, 4), (2, 70, 16), (2, 100, 32)]
 
 

@@ -35,7 +35,7 @@ OP_DDIM_UPDATE, OP_STEP_ADVANCE, OP_AUDIO_TO_INT16, OP_SPACE_TO_DEPTH, OP_DEPTH_
 OP_LINEAR, OP_FOURIER = 16, 17
 
 FLAG_GELU, FLAG_OUT_F32, FLAG_NOISE, FLAG_ADA, FLAG_LOG, FLAG_NO_EMBED, FLAG_GROUP_STATS, FLAG_WT = 1, 2, 4, 8, 16, 32, 64, 128
-FLAG_CAUSAL, FLAG_ELU = 256, 512
+FLAG_CAUSAL, FLAG_ELU, FLAG_FUSE_GN = 256, 512, 1024
 
 
 class AdkOp(C.Structure):
@@ -60,7 +60,7 @@ EXPORTS = [
     "adk_pack_input", "adk_pack_input_cond", "adk_unpack_output", "adk_pqmf_analysis", "adk_pqmf_synthesis",
     "adk_ddim_update", "adk_step_advance", "adk_audio_to_int16", "adk_space_to_depth", "adk_depth_to_space",
     "adk_attn1d_hd", "adk_adagn_apply", "adk_linear", "adk_fourier_features", "adk_pack_input_plain",
-    "adk_unpack_output_scaled", "adk_group_norm_noalloc",
+    "adk_unpack_output_scaled", "adk_group_norm_noalloc", "adk_conv_gn_fusable",
 ]
 
 _lib = None
@@ -91,6 +91,7 @@ def load():
     lib.adk_conv_postile.argtypes = [C.POINTER(AdkOp)]
     lib.adk_conv_cotile_used.argtypes = [C.POINTER(AdkOp)]
     lib.adk_conv_cotile.argtypes = [i32, i32, i32]
+    lib.adk_conv_gn_fusable.argtypes = [C.POINTER(AdkOp)]
     lib.adk_conv1d.argtypes = [i32, u32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.adk_gn_apply.argtypes = [i32, u32, i32, i32, i32, i32, f32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     lib.adk_gn_stats.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp]

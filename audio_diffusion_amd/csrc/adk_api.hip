@@ -11,6 +11,7 @@ int conv_cotile(int Cout);
 int conv_partials_count(const adk_op& op);
 int conv_postile(const adk_op& op);
 int conv_cotile_used(const adk_op& op);
+int conv_gn_check(const adk_op& op, const char** why);
 int launch_gn(const adk_op& op, hipStream_t st, bool apply);
 int gn_partials_count(int dtype, int C, int L);
 int launch_fir(const adk_op& op, hipStream_t st, bool up);
@@ -83,6 +84,15 @@ static int validate(const adk_op& o)
         REQUIRE(o.x && o.w && o.y, "conv1d: null tensor");
         REQUIRE(!(o.flags & ADK_FLAG_GROUP_STATS) || !(o.flags & ADK_FLAG_OUT_F32) || o.dtype == ADK_F32,
                 "conv1d: group statistics of an f32 output need dtype f32");
+        if (o.flags & ADK_FLAG_FUSE_GN) {
+            const char* why = "";
+            REQUIRE(conv_gn_check(o, &why), "conv1d + GroupNorm fusion: %s", why);
+            REQUIRE(o.gamma && o.beta && o.aux0 && o.aux1, "conv1d + GroupNorm fusion: needs gamma, beta, the epoch words (aux0) "
+                    "and the granule workspace (aux1)");
+            REQUIRE(o.f0 > 0.f, "conv1d + GroupNorm fusion: eps=%g", (double)o.f0);
+            REQUIRE(o.i1 >= 0 && o.i1 < 4095, "conv1d + GroupNorm fusion: slot %d outside [0, 4095)", o.i1);
+            REQUIRE(!o.partials_out || o.residual, "conv1d + GroupNorm fusion: output statistics are built for the residual form");
+        }
         return ADK_OK;
     }
     case ADK_OP_GN_APPLY:
@@ -263,6 +273,8 @@ int adk_conv_cotile_used(const adk_op* op) { return (op && op->kind == ADK_OP_CO
 int adk_conv_postile(const adk_op* op) { return (op && op->kind == ADK_OP_CONV) ? conv_postile(*op) : 0; }
 
 int adk_conv_cotile(int dtype, int Cout, int L) { (void)dtype; (void)L; return conv_cotile(Cout); }
+
+int adk_conv_gn_fusable(const adk_op* op) { return (op && op->kind == ADK_OP_CONV) ? conv_gn_check(*op, nullptr) : 0; }
 
 static adk_op zero_op(int kind, int dtype)
 {

@@ -10,6 +10,16 @@ struct ConvArgs {
     int gstats;                  // partials per 32-channel group (AdaGN / GroupNorm(C/32, C)) instead of per tile
     int shift, dil, elu;         // tap k reads row pos - shift + k*dil (centred: shift = taps/2; causal: (taps-1)*dil); ELU epilogue
     unsigned nblk;
+    // GroupNorm(1,C) [+ GELU] fused into the epilogue (ADK_FLAG_FUSE_GN, conv_mfma_gn.hip): the tiles of a sample exchange
+    // their (sum, sumsq) through 8-byte {epoch, value} granules in `gn_ws`
+    const float* gamma; const float* beta;
+    unsigned long long* gn_ws;   // [B][npb][2] granules
+    const unsigned* gn_epoch;    // [0] = per-forward epoch base (advanced by an earlier kernel); the tag also carries gn_slot
+    unsigned* gn_err;            // set to a non-zero code when a bounded wait runs out
+    unsigned* gn_ticket;         // this op's tile counter (grows by nblk per forward)
+    unsigned gn_slot;
+    int npb, gelu;               // tiles per sample (= tps * ncot)
+    float eps; double gn_count;  // Cout * L
 };
 
 template <typename T> struct Mma;
@@ -83,3 +93,5 @@ ConvTile conv_tile(const adk_op& op);
 void conv_fill_args(const adk_op& op, int BN, int BM, ConvArgs& a);
 int launch_conv_ksplit(const adk_op& op, hipStream_t st);
 int launch_conv_ext(const adk_op& op, hipStream_t st);      // conv_mfma_ext.hip
+int launch_conv_gn(const adk_op& op, hipStream_t st);       // conv_mfma_gn.hip
+int conv_gn_check(const adk_op& op, const char** why);      // host-only: can this conv op run with ADK_FLAG_FUSE_GN?

@@ -30,6 +30,47 @@ void conv_fill_args(const adk_op& op, int BN, int BM, ConvArgs& a)
     a.dil = op.i0 > 1 ? op.i0 : 1;
     a.shift = (op.flags & ADK_FLAG_CAUSAL) ? (op.taps - 1) * a.dil : (op.taps / 2) * a.dil;
     a.elu = (op.flags & ADK_FLAG_ELU) ? 1 : 0;
+    a.gamma = a.beta = nullptr; a.gn_ws = nullptr; a.gn_epoch = nullptr; a.gn_err = nullptr;
+    a.gn_slot = 0; a.gn_ticket = nullptr; a.npb = a.tps * a.ncot; a.gelu = 0; a.eps = 0.f; a.gn_count = 1.0;
+    if (op.flags & ADK_FLAG_FUSE_GN) {
+        a.gamma = op.gamma; a.beta = op.beta;
+        a.gn_ws = reinterpret_cast<unsigned long long*>(op.aux1);
+        a.gn_epoch = reinterpret_cast<const unsigned*>(op.aux0);
+        a.gn_err = const_cast<unsigned*>(reinterpret_cast<const unsigned*>(op.aux0)) + 1;
+        a.gn_slot = (unsigned)op.i1;
+        a.gn_ticket = a.gn_err + 1 + op.i1;                  // aux0 = {epoch base, error, ticket counters[4095]}
+        a.gelu = (op.flags & ADK_FLAG_GELU) ? 1 : 0;
+        a.eps = op.f0; a.gn_count = (double)op.Cout * (double)op.L;
+    }
+}
+
+// ADK_FLAG_FUSE_GN: which conv ops the fused conv + GroupNorm kernel takes (host-only; the launch re-checks the
+// resident-block capacity of the actual device).  512 = block slots of an MI355X (256 CUs x 2 blocks of this kernel).
+int launch_conv_gn_f32(const adk_op& op, hipStream_t st);
+int launch_conv_gn_bf16(const adk_op& op, hipStream_t st);
+int launch_conv_gn_f16(const adk_op& op, hipStream_t st);
+int conv_gn_check(const adk_op& op, const char** why)
+{
+    static const char* none = "";
+    const char* dummy;
+    if (!why) why = &dummy;
+    *why = none;
+    const ConvTile t = conv_tile(op);
+    if (t.ksplit || t.bn != 128) { *why = "only the pipelined 128-channel tiles (L > 128, Cout > 32)"; return 0; }
+    if (op.taps != 3 && op.taps != 5 && op.taps != 7) { *why = "taps must be 3, 5 or 7"; return 0; }
+    if ((op.flags & (ADK_FLAG_CAUSAL | ADK_FLAG_ELU | ADK_FLAG_GROUP_STATS | ADK_FLAG_OUT_F32)) || op.i0 > 1) {
+        *why = "not with causal / dilated / ELU / group-statistics / f32-output convs"; return 0;
+    }
+    const int npb = ((op.L + t.bm - 1) / t.bm) * (op.CoutPad / t.bn);
+    if (npb > 512) { *why = "more than 512 tiles per sample (they must all be in flight together)"; return 0; }
+    return 1;
+}
+
+int launch_conv_gn(const adk_op& op, hipStream_t st)
+{
+    if (op.dtype == ADK_F32) return launch_conv_gn_f32(op, st);
+    if (op.dtype == ADK_F16) return launch_conv_gn_f16(op, st);
+    return launch_conv_gn_bf16(op, st);
 }
 
 // tile-shape selection (host); adk_conv_cotile / adk_conv_postile / adk_partials_count report it.
@@ -78,6 +119,7 @@ static int launch_taps(const adk_op& op, hipStream_t st)
 int launch_conv(const adk_op& op, hipStream_t st)
 {
     const ConvTile ct = conv_tile(op);
+    if (op.flags & ADK_FLAG_FUSE_GN) return launch_conv_gn(op, st);
     if (ct.ksplit) return launch_conv_ksplit(op, st);
     if ((op.flags & (ADK_FLAG_CAUSAL | ADK_FLAG_ELU | ADK_FLAG_GROUP_STATS)) || op.i0 > 1) return launch_conv_ext(op, st);
     if (op.dtype == ADK_F32) return launch_taps<float, float>(op, st);

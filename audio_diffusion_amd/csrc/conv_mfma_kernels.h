@@ -329,8 +329,14 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_visible() {
     asm volatile("" ::: "memory");
 }
 
-template <bool EXT, typename T, typename TO, int TAPS, int WCO, int WPOS, int TCO, int TPOS, int DIL = 1>
-__global__ __launch_bounds__(WCO * WPOS * 64, (WCO * WPOS == 8 ? 1 : 2)) void conv_mfma_kernel(const ConvArgs a)
+// Everything of one output tile up to the end of its K loop (tile decode, prologue, pipelined phases, final block barrier);
+// shared by conv_mfma_kernel (one tile per block) and conv_mfma_gn_kernel (persistent blocks, GroupNorm fused into the
+// epilogue).  `lid` = logical tile id, co tile fastest, then position tile, then sample.
+struct ConvTileId { int b, t, cot, cobase, l0; };
+
+template <bool EXT, typename T, int TAPS, int WCO, int WPOS, int TCO, int TPOS, int DIL>
+__device__ __forceinline__ ConvTileId conv_tile_mainloop(const ConvArgs& a, const unsigned lid, unsigned char* smem,
+                                                         f32x16 (&acc)[TCO][TPOS], const int tid)
 {
     constexpr int BN = WCO * TCO * 32, BM = WPOS * TPOS * 32;
     constexpr int NW = WCO * WPOS;               // waves per block: 4 (two blocks per CU) or 8 (one block per CU)
@@ -358,11 +364,9 @@ __global__ __launch_bounds__(WCO * WPOS * 64, (WCO * WPOS == 8 ? 1 : 2)) void co
         g_adk_ts[blockIdx.x * 8 + 3] = ((unsigned long long)xcc << 32) | hwid;
     }
 #endif
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xs = smem;                    // [RX][XBYTES]
     unsigned char* ws = smem + RX * XBYTES;      // [RW][WBYTES]
 
-    const unsigned lid = xcd_remap(blockIdx.x, a.nblk);
     const int cot = (int)(lid % (unsigned)a.ncot);
     const unsigned r1 = lid / (unsigned)a.ncot;
     const int t = (int)(r1 % (unsigned)a.tps);
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(WCO * WPOS * 64, (WCO * WPOS == 8 ? 1 : 2)) void co
     const int l0 = t * BM;
     const long long mrow0 = (long long)b * a.Lp + a.P + l0 - (EXT ? a.shift : TAPS / 2);   // EXT: causal / dilated taps
 
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wco = wave / WPOS, wpos = wave % WPOS;
     const int srow = lane >> 2, sslot = lane & 3;
@@ -382,7 +386,6 @@ __global__ __launch_bounds__(WCO * WPOS * 64, (WCO * WPOS == 8 ? 1 : 2)) void co
     const long long wchunk = (long long)TAPS * a.CoutPad * 64;
     const int total = a.nchunks * TAPS;
 
-    f32x16 acc[TCO][TPOS];
     float4 bv[TCO][4];
     conv_bias_fetch<TCO>(a, bv, cobase, wco, h);           // bias loads go out first (see conv_bias_fetch)
 
@@ -481,8 +484,22 @@ __global__ __launch_bounds__(WCO * WPOS * 64, (WCO * WPOS == 8 ? 1 : 2)) void co
 #undef ADK_MMA_ALL
     __syncthreads();      // all fragment reads done before the epilogue reuses LDS for its reduction
     ADK_TS(1)
+    ConvTileId id;
+    id.b = b; id.t = t; id.cot = cot; id.cobase = cobase; id.l0 = l0;
+    return id;
+}
 
-    conv_epilogue<EXT, TO, BN, BM, WPOS, TCO, TPOS>(a, acc, smem, b, t, cot, cobase, l0, tid, l31, h, wco, wpos);
+template <bool EXT, typename T, typename TO, int TAPS, int WCO, int WPOS, int TCO, int TPOS, int DIL = 1>
+__global__ __launch_bounds__(WCO * WPOS * 64, (WCO * WPOS == 8 ? 1 : 2)) void conv_mfma_kernel(const ConvArgs a)
+{
+    constexpr int BN = WCO * TCO * 32, BM = WPOS * TPOS * 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f32x16 acc[TCO][TPOS];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const ConvTileId id = conv_tile_mainloop<EXT, T, TAPS, WCO, WPOS, TCO, TPOS, DIL>(a, xcd_remap(blockIdx.x, a.nblk), smem, acc, tid);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave / WPOS, wpos = wave % WPOS;
+    conv_epilogue<EXT, TO, BN, BM, WPOS, TCO, TPOS>(a, acc, smem, id.b, id.t, id.cot, id.cobase, id.l0, tid, l31, h, wco, wpos);
 #ifdef ADK_ABL_TS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif

@@ -86,6 +86,11 @@ class _Plan:
         self.meta = []            # per-op bookkeeping for profiling (algorithmic FLOPs / bytes)
         self._keep = []           # device tensors that must outlive the plan (weights, tables)
         self.t_table = t_table
+        # conv + GroupNorm fusion (ADK_FLAG_FUSE_GN, include/adk.h): state words {epoch, error, counters[4095]} and the
+        # statistics-exchange workspace, both allocated first and never released (the arena starts zeroed)
+        self.fuse_gn = bool(getattr(model, "fuse_gn", True))
+        self._gn_state = self._gn_ws = None
+        self._gn_slots = 0
         self._build()
         self._finalize()
 
@@ -152,8 +157,30 @@ class _Plan:
         self.meta.append({"kind": kind})
         return op
 
+    def _gn_regions(self):
+        """First fused conv of the plan: the state / workspace regions and the op that advances the forward counter."""
+        if self._gn_state is None:
+            self._gn_state = self.raw(16 * 1024 + 16)
+            self._gn_ws = self.raw(self.B * 512 * 16)
+            self._emit(_lib.OP_STEP_ADVANCE, {"y": ("arena", self._gn_state.off)})
+            self._ops.insert(0, self._ops.pop())             # before everything else of the forward
+            self.meta.insert(0, self.meta.pop())
+        return self._gn_state, self._gn_ws
+
+    def gn_fusable(self, x, w, Cout, out_f32=False):
+        """Can conv(x, w) -> GroupNorm(1, Cout) run as ONE launch (adk_conv_gn_fusable)?"""
+        if not self.fuse_gn or out_f32 or self._gn_slots >= 4094:
+            return False
+        op = _lib.AdkOp()
+        op.kind, op.dtype, op.B, op.L, op.P = _lib.OP_CONV, self.adk_dtype, self.B, x.L, self.P
+        op.Cout, op.taps = Cout, w.shape[2]
+        op.CoutPad = _ceil_to(Cout, self.lib.adk_conv_cotile(self.adk_dtype, Cout, x.L))
+        return bool(self.lib.adk_conv_gn_fusable(ctypes.byref(op)))
+
     def conv(self, x, key, w, bias, Cout, out=None, residual=None, stats=False, out_f32=False, gstats=False,
-             dilation=1, causal=False, elu=False):
+             dilation=1, causal=False, elu=False, gn=None):
+        """``gn = (key, gamma, beta, gelu)``: GroupNorm(1, Cout) [+ GELU] fused into the conv's epilogue; ``residual``
+        is then added AFTER norm + activation and ``stats`` are those of the final output."""
         taps = w.shape[2]
         bn = self.lib.adk_conv_cotile(self.adk_dtype, Cout, x.L)
         cout_pad = _ceil_to(Cout, bn)
@@ -172,13 +199,25 @@ class _Plan:
             flags |= _lib.FLAG_CAUSAL
         if elu:
             flags |= _lib.FLAG_ELU
+        extra = {}
+        if gn is not None:
+            gkey, gamma, beta, gelu = gn
+            state, ws = self._gn_regions()
+            flags |= _lib.FLAG_FUSE_GN | (_lib.FLAG_GELU if gelu else 0)
+            ptrs["gamma"] = ("abs", self._padded_vec(gkey + ".weight", gamma, cout_pad))
+            ptrs["beta"] = ("abs", self._padded_vec(gkey + ".bias", beta, cout_pad))
+            ptrs["aux0"], ptrs["aux1"] = ("arena", state.off), ("arena", ws.off)
+            extra = dict(i1=self._gn_slots, f0=GN_EPS)
+            self._gn_slots += 1
         op = self._emit(_lib.OP_CONV, ptrs, flags=flags, L=x.L, Cin=cin_alloc, Cout=Cout, CoutPad=cout_pad, taps=taps,
-                        i0=dilation if dilation > 1 else 0)
+                        i0=dilation if dilation > 1 else 0, **extra)
         self.meta[-1].update(taps=taps, L=x.L, cin=w.shape[1], cout=Cout, cotile=self.lib.adk_conv_cotile_used(ctypes.byref(op)),
                              postile=self.lib.adk_conv_postile(ctypes.byref(op)),
                              flops=2.0 * w.shape[1] * Cout * taps * x.L * self.B,
                              bytes=float(self.B) * x.L * (cin_alloc * (4 if x.f32 else 2) + Cout * (4 if y.f32 else 2))
-                             + float(cin_alloc) * cout_pad * taps * (4 if x.f32 else 2))
+                             + float(cin_alloc) * cout_pad * taps * (4 if x.f32 else 2)
+                             + (float(self.B) * x.L * Cout * (4 if y.f32 else 2) if (gn is not None and residual is not None) else 0.0),
+                             fused_gn=gn is not None)
         part = None
         if stats:
             n = self.lib.adk_partials_count(ctypes.byref(op))
@@ -260,9 +299,13 @@ class _Plan:
     def res_block(self, blk, key, x, out=None, stats=False):
         """ResConvBlock (reference blocks/blocks.py:66-76,14-15).  Does not free x."""
         c1, g1, c2 = blk.main[0], blk.main[1], blk.main[3]
-        raw1, p1 = self.conv(x, key + "main.0", c1.weight, c1.bias, blk.c_mid, stats=True)
-        h1, _ = self.gn_apply(raw1, p1, key + "main.1", g1.weight, g1.bias, gelu=True)
-        self.free(p1)
+        if self.gn_fusable(x, c1.weight, blk.c_mid):         # conv -> GroupNorm -> GELU as one launch
+            h1, _ = self.conv(x, key + "main.0", c1.weight, c1.bias, blk.c_mid,
+                              gn=(key + "main.1", g1.weight, g1.bias, True))
+        else:
+            raw1, p1 = self.conv(x, key + "main.0", c1.weight, c1.bias, blk.c_mid, stats=True)
+            h1, _ = self.gn_apply(raw1, p1, key + "main.1", g1.weight, g1.bias, gelu=True)
+            self.free(p1)
         has_skip = isinstance(blk.skip, nn.Conv1d)
         if blk.is_last:
             if has_skip:
@@ -273,12 +316,22 @@ class _Plan:
             y, _ = self.conv(h1, key + "main.3", c2.weight, c2.bias, blk.c_out, residual=r, out_f32=True, out=out)
             self.free(h1, r)
             return y, None
+        g2 = blk.main[4]
+        if self.gn_fusable(h1, c2.weight, blk.c_out):        # conv -> GroupNorm -> GELU -> + skip(x) as one launch
+            r = x
+            if has_skip:
+                r, _ = self.conv(x, key + "skip", blk.skip.weight, None, blk.c_out)
+            y, pout = self.conv(h1, key + "main.3", c2.weight, c2.bias, blk.c_out, out=out, residual=r, stats=stats,
+                                gn=(key + "main.4", g2.weight, g2.bias, True))
+            self.free(h1)
+            if has_skip:
+                self.free(r)
+            return y, pout
         raw2, p2 = self.conv(h1, key + "main.3", c2.weight, c2.bias, blk.c_out, stats=True)
         self.free(h1)
         r = x
         if has_skip:
             r, _ = self.conv(x, key + "skip", blk.skip.weight, None, blk.c_out)
-        g2 = blk.main[4]
         y, pout = self.gn_apply(raw2, p2, key + "main.4", g2.weight, g2.bias, gelu=True, residual=r, out=out, stats=stats)
         self.free(p2)
         if has_skip:
@@ -430,6 +483,12 @@ class _Plan:
 
     def run(self, stream_ptr):
         _lib.run_ops(self.ops, self.n_ops, stream_ptr)
+
+    def gn_error(self):
+        """Error word of the fused conv + GroupNorm kernels (0 = fine).  Synchronises; for tests and benchmarks."""
+        if self._gn_state is None:
+            return 0
+        return int(self.arena[self._gn_state.off + 4:self._gn_state.off + 8].view(torch.int32).item())
 
     def validate(self):
         """Host-only check of every op descriptor (adk_validate_plan); launches nothing."""

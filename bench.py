@@ -280,6 +280,7 @@ def main():
     ap.add_argument("--cpu-calls", type=int, default=4, help="denoiser calls timed for cpu_baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the accuracy object and the fp32 / bf16 sub-records")
+    ap.add_argument("--no-fuse-gn", action="store_true", help="A/B: GroupNorm as passes of its own (the round-1 plan)")
     ap.add_argument("--backend", default=None, help="nccl (= RCCL, default on GPUs) or gloo (CPU rehearsal of the launcher)")
     ap.add_argument("--standin", action="store_true",
                     help="CPU rehearsal: a stand-in per-sample function replaces the HIP sampler (launcher, sharding, "
@@ -330,6 +331,7 @@ def main():
             cpu = cpu_baseline(model, a.cpu_calls, host_cpu_budget())
         model = model.to(dev)
         model.compute_dtype = dtype
+        model.fuse_gn = not a.no_fuse_gn
         sampler = A.sample
 
     # noise generated ONCE from a single CPU seed and sliced per rank: a sample's result does not depend on N
@@ -395,6 +397,9 @@ def main():
                 for other in ("fp32", "bf16", "f16"):
                     if other != a.dtype and (other == "fp32" or a.dtype == "f16"):
                         rec[other] = timed_pass(model, x, DT[other], a.ddim_steps, dev)
+            errs = [p.plan.gn_error() if hasattr(p, "plan") else p.gn_error() for p in model._plans.values()]
+            assert not any(errs), f"fused conv + GroupNorm kernels flagged an error: {errs}"
+            rec["config"]["groupnorm"] = "fused into the producing conv's epilogue" if model.fuse_gn else "separate passes"
             if cpu is not None:
                 rec["cpu_baseline"] = cpu
         print(json.dumps(rec), flush=True)

@@ -79,6 +79,19 @@ enum {
                                    [B][ceil(Cout/32)][adk_partials_count / groups][2], for a following
                                    AdaGN / GroupNorm(C/32, C) (blocks/blocks.py:63, 93, 97)          */
 
+#define ADK_FLAG_FUSE_GN 1024u   /* CONV: y = [GELU](GroupNorm(1, Cout)(conv(x) + bias)) [+ residual] in ONE launch
+                                   (blocks/blocks.py:70-75 and the residual add of :14-15): gamma / beta f32 [CoutPad]
+                                   (zero beyond Cout), f0 = eps, ADK_FLAG_GELU selects the activation, `residual` is added
+                                   AFTER norm + activation, partials_out (optional, residual form only) = statistics of y.
+                                   aux1 = workspace of B * tiles-per-sample * 16 bytes, any contents, may be shared by the
+                                   fused convs of a stream; aux0 = uint32 words {epoch base, error, counters[4095]}, 16 KiB,
+                                   zero-initialised ONCE: adk_step_advance on the epoch base once per forward (before the
+                                   first fused conv), every fused conv of the forward with its own i1 = slot in [0, 4095),
+                                   every one of them run exactly once per forward (tiles are handed out by counters[slot],
+                                   which grows by the tile count per forward).  The error word becomes non-zero if a tile
+                                   waited in vain for its sample's other tiles or the counters are out of step.
+                                   Only where adk_conv_gn_fusable(). */
+
 /* One flat descriptor for every op kind; unused fields are 0/NULL.  Field use per kind is
  * documented at the matching adk_* entry point below (same names). */
 typedef struct adk_op {
@@ -114,6 +127,10 @@ int adk_partials_count(const adk_op *op);
 int adk_conv_postile(const adk_op *op);
 /* Output channels per block (32, 128 or 256) the conv kernel will use for this op. */
 int adk_conv_cotile_used(const adk_op *op);
+
+/* 1 if the conv op (dtype, B, L, Cout, CoutPad, taps, flags filled in) can run with ADK_FLAG_FUSE_GN: the pipelined
+ * 128-channel tile (L > 128, Cout > 32), taps 3 / 5 / 7, at most 512 tiles per sample.  Host-only. */
+int adk_conv_gn_fusable(const adk_op *op);
 
 /* Co-tile (rows of packed weight must be a multiple of this) the conv kernel will use. */
 int adk_conv_cotile(int dtype, int Cout, int L);

@@ -332,6 +332,96 @@ def test_attention_core(env, dt, B, heads, s):
     assert float(full[:, :, :P].abs().max()) == 0.0 and float(full[:, :, P + s:].abs().max()) == 0.0, "halo rows not zero"
 
 
+FUSED_CASES = [
+    # B, L, Cin, Cout, taps, residual, stats
+    (3, 300, 64, 128, 5, False, False),     # 128x128 tiles, ragged, one round
+    (2, 200, 32, 96, 5, True, True),        # 128x64 tile, Cout not a tile multiple (pad channels stay zero)
+    (20, 16384, 32, 128, 5, True, False),   # 1280 tiles of 128x256: more tiles than block slots, 64 tiles per sample
+    (2, 65536, 32, 128, 5, False, False),   # 256 tiles per sample (level 1 of the uncond model)
+    (5, 4100, 64, 256, 3, True, True),      # two co tiles per position tile, ragged last tile, 3 taps
+    (2, 1000, 96, 160, 7, True, False),     # 7 taps, halo 3
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("case", FUSED_CASES, ids=[f"case{i}" for i in range(len(FUSED_CASES))])
+def test_conv_groupnorm_gelu_fused(env, dt, case):
+    """ADK_FLAG_FUSE_GN: conv -> GroupNorm(1, C) -> GELU (-> + residual) in one launch (the tiles of a sample exchange
+    their statistics inside the launch) against the fp32 CPU composition of the same ATen ops, run twice with the
+    forward counter advanced in between (bit-identical), and once more WITHOUT advancing it (must flag, not hang)."""
+    lib, _lib, layout, dev = env
+    dtype, adk, tol = DT[dt]
+    B, L, Cin, Cout, taps, res, stats = case
+    P = taps // 2
+    cb = layout.chunk(dtype)
+    g = torch.Generator().manual_seed(100 + L + Cout)
+    x = torch.randn(B, Cin, L, generator=g)
+    w = torch.randn(Cout, Cin, taps, generator=g) / (Cin * taps) ** 0.5
+    bias = torch.randn(Cout, generator=g) * 0.3
+    gamma, beta = torch.randn(Cout, generator=g) * 0.5 + 1.0, torch.randn(Cout, generator=g) * 0.2
+    r = torch.randn(B, Cout, L, generator=g) if res else None
+    xq, wq = quant(x, dtype), quant(w, dtype)
+    ref = F.gelu(F.group_norm(F.conv1d(xq, wq, bias, padding=P), 1, gamma, beta, 1e-5))
+    if res:
+        ref = ref + quant(r, dtype)
+    cout_pad = (Cout + 127) // 128 * 128
+    xd = layout.to_cpl(x.to(dev), dtype, P)
+    wd = pack_w(w, Cin, cout_pad, cb, dtype, dev)
+    bd, gd, btd = (torch.zeros(cout_pad, device=dev) for _ in range(3))
+    bd[:Cout], gd[:Cout], btd[:Cout] = bias.to(dev), gamma.to(dev), beta.to(dev)
+    rd = layout.to_cpl(r.to(dev), dtype, P) if res else None
+    planes = (Cout + cb - 1) // cb
+    state = torch.zeros(4096 + 4, dtype=torch.int32, device=dev)
+    ws = torch.full((B * 512 * 2,), -1, dtype=torch.int64, device=dev)          # any contents
+    op = _lib.AdkOp()
+    op.kind, op.dtype, op.flags = _lib.OP_CONV, adk, _lib.FLAG_FUSE_GN | _lib.FLAG_GELU
+    op.B, op.L, op.P, op.Cin, op.Cout, op.CoutPad, op.taps = B, L, P, Cin, Cout, cout_pad, taps
+    op.i1, op.f0 = 7, 1e-5
+    assert lib.adk_conv_gn_fusable(C.byref(op)) == 1
+    npart = ((L + lib.adk_conv_postile(C.byref(op)) - 1) // lib.adk_conv_postile(C.byref(op))) * (cout_pad // 128)
+    pout = torch.zeros(B, npart, 2, device=dev) if stats else None
+    op.x, op.w, op.bias, op.gamma, op.beta = xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), gd.data_ptr(), btd.data_ptr()
+    op.residual = rd.data_ptr() if res else None
+    op.partials_out = pout.data_ptr() if stats else None
+    op.aux0, op.aux1 = state.data_ptr(), ws.data_ptr()
+    outs = []
+    for _ in range(2):
+        yd = torch.full((planes, B, L + 2 * P, cb), 3.0, dtype=dtype, device=dev)
+        op.y = yd.data_ptr()
+        assert lib.adk_step_advance(state.data_ptr(), sp()) == 0
+        assert lib.adk_run_plan(C.byref(op), 1, sp()) == 0, lib.adk_last_error()
+        torch.cuda.synchronize()
+        assert int(state[1].item()) == 0, "a tile waited in vain for its sample's statistics"
+        outs.append(yd)
+    assert torch.equal(outs[0].view(torch.uint8), outs[1].view(torch.uint8)), "reruns must be bit-identical"
+    full = layout.from_cpl(outs[0], planes * cb).cpu()
+    assert rel_err(full[:, :Cout, P:P + L], ref) <= (2e-5 if dt == "f32" else tol)
+    assert float(full[:, Cout:].abs().max() if planes * cb > Cout else 0.0) == 0.0, "pad channels must stay zero"
+    assert float(full[:, :, :P].abs().max()) == 0.0 and float(full[:, :, P + L:].abs().max()) == 0.0, "halo rows not zero"
+    if stats:
+        so = pout.double().sum(1).cpu()
+        assert torch.allclose(so[:, 0], ref.double().sum((1, 2)), rtol=5e-3, atol=5e-3 * ref.abs().sum((1, 2)).max().item())
+        assert torch.allclose(so[:, 1], ref.double().pow(2).sum((1, 2)), rtol=5e-3)
+    # the same op again without advancing the forward counter: every ticket is out of range -> flagged, nothing hangs
+    assert lib.adk_run_plan(C.byref(op), 1, sp()) == 0
+    torch.cuda.synchronize()
+    assert int(state[1].item()) != 0
+
+
+def test_conv_groupnorm_fusion_argument_checks(env):
+    lib, _lib, layout, dev = env
+    op = _lib.AdkOp()
+    op.kind, op.dtype, op.flags = _lib.OP_CONV, 1, _lib.FLAG_FUSE_GN
+    op.B, op.L, op.P, op.Cin, op.Cout, op.CoutPad, op.taps = 2, 64, 2, 32, 128, 128, 5
+    assert lib.adk_conv_gn_fusable(C.byref(op)) == 0          # short level: k-split kernel, not fusable
+    op.L = 262144                                             # 1024 tiles per sample: more than the GPU holds at once
+    assert lib.adk_conv_gn_fusable(C.byref(op)) == 0
+    op.L = 4096
+    assert lib.adk_conv_gn_fusable(C.byref(op)) == 1
+    op.x = op.w = op.y = 256
+    assert lib.adk_validate_plan(C.byref(op), 1) == -1        # gamma / beta / state / workspace missing
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 def test_attention_bits_reproducible(env, dt):
     """The MFMA attention kernel packs its probabilities with the one-instruction conversion right after packed-f32

@@ -159,17 +159,22 @@ class _Plan:
 
     def _gn_regions(self):
         """First fused conv of the plan: the state / workspace regions and the op that advances the forward counter."""
-        if self._gn_state is None:
-            self._gn_state = self.raw(16 * 1024 + 16)
-            self._gn_ws = self.raw(self.B * 512 * 16)
+        if not self._gn_slots:
             self._emit(_lib.OP_STEP_ADVANCE, {"y": ("arena", self._gn_state.off)})
             self._ops.insert(0, self._ops.pop())             # before everything else of the forward
             self.meta.insert(0, self.meta.pop())
         return self._gn_state, self._gn_ws
 
+    def _gn_reserve(self):
+        """Called before anything else is planned: the two regions must never share bytes with a buffer of the forward
+        (a region taken later could land in a hole a released activation left, and that activation's producer would
+        then overwrite the counters on every call)."""
+        self._gn_state = self.raw(16 * 1024 + 16)
+        self._gn_ws = self.raw(self.B * 512 * 16)
+
     def gn_fusable(self, x, w, Cout, out_f32=False):
         """Can conv(x, w) -> GroupNorm(1, Cout) run as ONE launch (adk_conv_gn_fusable)?"""
-        if not self.fuse_gn or out_f32 or self._gn_slots >= 4094:
+        if not self.fuse_gn or out_f32 or self._gn_slots >= 4094 or self._gn_state is None:
             return False
         op = _lib.AdkOp()
         op.kind, op.dtype, op.B, op.L, op.P = _lib.OP_CONV, self.adk_dtype, self.B, x.L, self.P
@@ -393,6 +398,8 @@ class _Plan:
 
     def _build(self):
         m, B = self.model, self.B
+        if self.fuse_gn:
+            self._gn_reserve()
         bands = m.pqmf_bands
         L0 = self.T // bands
         cx = m.io_channels * bands

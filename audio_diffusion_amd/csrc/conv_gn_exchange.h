@@ -1,0 +1,73 @@
+// Exchange of GroupNorm statistics between the tiles of one sample INSIDE a launch (ADK_FLAG_FUSE_GN; the design and
+// its deadlock argument: conv_mfma_gn.inc).  cdna_hip_programming.md, Guideline 16, form R2: naturally aligned 8-byte
+// {tag = epoch, value} granules, one agent-scope store each, re-read with agent-scope loads by ONE wave until every
+// tag matches; no fence, no flag, nothing to zero (the epoch is unique per launch).
+#pragma once
+#include "conv_common.h"
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+#define ADK_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+constexpr unsigned GN_SPIN_LIMIT = 1u << 20;     // ~1 us per poll: gives up after about a second
+constexpr int GN_MAX_NPB = 512;                  // tiles per sample: 2 * 512 granules = 16 per lane of the sweeping wave
+
+// One lane publishes this tile's (sum, sumsq).
+__device__ __forceinline__ void gn_publish(const ConvArgs& a, int b, int tile, unsigned epoch, float s1, float s2)
+{
+    gu64* g = (gu64*)(a.gn_ws) + ((size_t)b * a.npb + (size_t)tile) * 2;
+    __hip_atomic_store(g, ((unsigned long long)epoch << 32) | __float_as_uint(s1), ADK_RLX_AGENT);
+    __hip_atomic_store(g + 1, ((unsigned long long)epoch << 32) | __float_as_uint(s2), ADK_RLX_AGENT);
+}
+
+// ONE wave (all 64 lanes) gathers the sample's granules and returns mean / rstd on every lane.  Lane parity: even lanes
+// read sums, odd lanes sums of squares; both are added in granule order in double, whatever the arrival order.
+__device__ __forceinline__ void gn_gather(const ConvArgs& a, int b, unsigned epoch, int lane, float& mean, float& rstd)
+{
+    gu64* gs = (gu64*)(a.gn_ws) + (size_t)b * a.npb * 2;
+    const int ng = 2 * a.npb;
+    double acc_d = 0.0;
+    for (unsigned spins = 0;;) {
+        unsigned long long x[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int idx = lane + 64 * k;
+            x[k] = idx < ng ? __hip_atomic_load(gs + idx, ADK_RLX_AGENT) : ((unsigned long long)epoch << 32);
+        }
+        bool ok = true;
+        acc_d = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            ok &= (unsigned)(x[k] >> 32) == epoch;
+            acc_d += (double)__uint_as_float((unsigned)x[k]);
+        }
+        if (__all(ok)) break;
+        if (++spins >= GN_SPIN_LIMIT) {               // bounded: a block that is not resident must not hang the GPU
+            if (lane == 0) __hip_atomic_store((gu32*)(a.gn_err), 0x600du + 1u, ADK_RLX_AGENT);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+#pragma unroll
+    for (int o = 32; o >= 2; o >>= 1) acc_d += __shfl_xor(acc_d, o, 64);        // within each parity class
+    const double q = __shfl(acc_d, 1, 64), tot = __shfl(acc_d, 0, 64);
+    const double mu = tot / a.gn_count;
+    double var = q / a.gn_count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean = (float)mu;
+    rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+}
+
+// publish + gather + broadcast to the block through two LDS words (red[8], red[9]); every thread calls it.
+__device__ __forceinline__ void gn_exchange(const ConvArgs& a, int b, int tile, unsigned epoch, float s1, float s2,
+                                            float* red, int tid, float& mean, float& rstd)
+{
+    if (tid == 0) gn_publish(a, b, tile, epoch, s1, s2);
+    if ((tid >> 6) == 0) {
+        float mu, rs;
+        gn_gather(a, b, epoch, tid & 63, mu, rs);
+        if (tid == 0) { red[8] = mu; red[9] = rs; }
+    }
+    __syncthreads();
+    mean = red[8]; rstd = red[9];
+}

@@ -10,9 +10,16 @@
 // and are summed in FIXED wave order (bit-reproducible); wave w finishes channel group 8w..8w+3 (+4h) of
 // every 32-channel sub-tile: + bias, + residual, GroupNorm partials, halo rows, store.
 // Same packed weights, same CPL activations, same epilogue semantics as conv_mfma.hip.
+//
+// GN = true (ADK_FLAG_FUSE_GN): GroupNorm(1,C) + GELU (+ residual) ride in the epilogue, as in conv_mfma_gn.inc: the
+// blocks of a sample exchange their (sum, sumsq) through epoch-tagged granules inside the launch.  A grid that fits the
+// GPU (B = 16: 256 blocks) keeps its co-tile-major block order - every block is resident, so any order is safe; a
+// larger grid hands its tiles out by ticket in sample-major start order (conv_mfma_gn.inc has the argument).
+#include <stdlib.h>
 #include "conv_common.h"
+#include "conv_gn_exchange.h"
 
-template <typename T, typename TO, int TAPS, int TCO, int TPOS, int DEPTH>
+template <typename T, typename TO, int TAPS, int TCO, int TPOS, int DEPTH, bool GN>
 __global__ __launch_bounds__(256, (TCO * TPOS >= 4 ? 1 : 2)) void conv_ksplit_kernel(const ConvArgs a)
 {
     constexpr int BN = TCO * 32, BM = TPOS * 32, S = TCO * TPOS;
@@ -23,12 +30,35 @@ __global__ __launch_bounds__(256, (TCO * TPOS >= 4 ? 1 : 2)) void conv_ksplit_ke
 
     // co-tile-major logical order: after the XCD remap an XCD owns a contiguous range of co tiles, so each of
     // the 8 L2s fetches only its share of the weights (which come from HBM on every denoiser call)
-    const unsigned lid = xcd_remap(blockIdx.x, a.nblk);
+    unsigned lid = xcd_remap(blockIdx.x, a.nblk);
     const unsigned nbt = (unsigned)(a.B * a.tps);
-    const int cot = (int)(lid / nbt);
-    const unsigned r1 = lid % nbt;
-    const int t = (int)(r1 % (unsigned)a.tps);
-    const int b = (int)(r1 / (unsigned)a.tps);
+    int cot = (int)(lid / nbt);
+    unsigned r1 = lid % nbt;
+    int t = (int)(r1 % (unsigned)a.tps);
+    int b = (int)(r1 / (unsigned)a.tps);
+    unsigned epoch = 0;
+    if constexpr (GN) {
+        const unsigned ebase = a.gn_epoch[0];
+        epoch = ebase * 4096u + a.gn_slot + 1u;
+        if (a.nblk > a.gn_cap) {                             // not all blocks resident at once: tiles by ticket, sample-major
+            unsigned* tick = reinterpret_cast<unsigned*>(smem);
+            if (threadIdx.x == 0) {
+                const unsigned old = __hip_atomic_fetch_add((gu32*)(a.gn_ticket), 1u, ADK_RLX_AGENT);
+                *tick = old - (ebase - 1u) * a.nblk;
+            }
+            __syncthreads();
+            lid = __builtin_amdgcn_readfirstlane(*tick);
+            __syncthreads();
+            if (lid >= a.nblk) {
+                if (threadIdx.x == 0) __hip_atomic_store((gu32*)(a.gn_err), 0x71c1u, ADK_RLX_AGENT);
+                return;
+            }
+            b = (int)(lid / (unsigned)a.npb);
+            r1 = lid % (unsigned)a.npb;
+            cot = (int)(r1 / (unsigned)a.tps);
+            t = (int)(r1 % (unsigned)a.tps);
+        }
+    }
     const int cobase = cot * BN;
     const int l0 = t * BM;
     const int mrow0 = b * a.Lp + a.P + l0 - a.shift;           // >= 0: P >= shift (validated on the host)
@@ -137,6 +167,96 @@ __global__ __launch_bounds__(256, (TCO * TPOS >= 4 ? 1 : 2)) void conv_ksplit_ke
     // wave w now owns D[co = cobase + 32 i + 8 w + 4 h + e][pos = l0 + 32 j + l31]
     TO* yg = reinterpret_cast<TO*>(a.y);
     const TO* rg = reinterpret_cast<const TO*>(a.residual);
+    if constexpr (GN) {
+        // raw = conv + bias stays in registers (S x 4 values per lane) across the exchange of the sample statistics
+        float vv[TCO][TPOS][4];
+        float4 gm[TCO], bt[TCO];
+        float r1s = 0.f, r2s = 0.f;
+#pragma unroll
+        for (int i = 0; i < TCO; ++i) {
+            const int c = cobase + i * 32 + 8 * wave + 4 * h;
+            gm[i] = *reinterpret_cast<const float4*>(a.gamma + c);
+            bt[i] = *reinterpret_cast<const float4*>(a.beta + c);
+        }
+#pragma unroll
+        for (int j = 0; j < TPOS; ++j) {
+            const bool lvalid = l0 + j * 32 + l31 < a.L;
+#pragma unroll
+            for (int i = 0; i < TCO; ++i) {
+                const int co = cobase + i * 32 + 8 * wave + 4 * h;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sw = 0; sw < 4; ++sw) {
+                    const float4 p = red[((sw * S + i * TPOS + j) * 4 + wave) * 64 + lane];
+                    v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
+                }
+                v[0] += bpre[i].x; v[1] += bpre[i].y; v[2] += bpre[i].z; v[3] += bpre[i].w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    vv[i][j][e] = v[e];
+                    if (lvalid && co < a.Cout_alloc) { r1s += v[e]; r2s += v[e] * v[e]; }
+                }
+            }
+        }
+        float* redf = reinterpret_cast<float*>(smem);
+        block_sum2(r1s, r2s, redf);                         // starts with a barrier: the reads of `red` are done
+        float mean, rstd;
+        gn_exchange(a, b, t * a.ncot + cot, epoch, r1s, r2s, redf, tid, mean, rstd);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < TPOS; ++j) {
+            const int l = l0 + j * 32 + l31;
+            const bool lvalid = l < a.L;
+            const long long m = (long long)b * a.Lp + a.P + l;
+#pragma unroll
+            for (int i = 0; i < TCO; ++i) {
+                const int co = cobase + i * 32 + 8 * wave + 4 * h;
+                if (lvalid && co < a.Cout_alloc) {
+                    const float g4[4] = {gm[i].x, gm[i].y, gm[i].z, gm[i].w}, b4[4] = {bt[i].x, bt[i].y, bt[i].z, bt[i].w};
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float sc = g4[e] * rstd, sh = b4[e] - mean * sc;
+                        v[e] = vv[i][j][e] * sc + sh;
+                        if (a.gelu) v[e] = gelu_for<T>(v[e]);
+                    }
+                    if (rg) {
+                        float rr[4];
+                        raw_to_float4(rpre[i][j], rr, TO());
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rr[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { s1 += v[e]; s2 += v[e] * v[e]; }
+                    const long long off = (((long long)(co / CBO) * a.M + m) * CBO) + (co % CBO);
+                    store4(yg + off, v);
+                }
+            }
+        }
+        if (t == 0 || t == a.tps - 1) {
+            const int plane0 = cobase / CBO;
+            const int cend = cobase + BN < a.Cout_alloc ? cobase + BN : a.Cout_alloc;
+            const int nplanes = (cend + CBO - 1) / CBO - plane0;
+            const int per = a.P * 4;
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            unsigned char* yb = reinterpret_cast<unsigned char*>(a.y);
+            for (int p = tid; p < nplanes * per; p += 256) {
+                const int pl = plane0 + p / per, rem = p % per, row = rem >> 2, q = rem & 3;
+                const long long mh = (long long)b * a.Lp + row;
+                if (t == 0) *reinterpret_cast<uint4*>(yb + ((long long)pl * a.M + mh) * 64 + q * 16) = z;
+                if (t == a.tps - 1)
+                    *reinterpret_cast<uint4*>(yb + ((long long)pl * a.M + mh + a.P + a.L) * 64 + q * 16) = z;
+            }
+        }
+        if (a.partials) {                                    // statistics of the output, for a following attention norm
+            block_sum2(s1, s2, redf);
+            if (tid == 0) {
+                float* dst = a.partials + ((long long)(b * a.tps + t) * a.ncot + cot) * 2;
+                dst[0] = s1; dst[1] = s2;
+            }
+        }
+        return;
+    }
     float s1 = 0.f, s2 = 0.f;
     float gs1[TCO], gs2[TCO];
 #pragma unroll
@@ -219,7 +339,28 @@ static int launch_ks(const adk_op& op, hipStream_t st)
     ConvArgs a;
     conv_fill_args(op, TCO * 32, TPOS * 32, a);
     const size_t lds = (size_t)TCO * TPOS * 16384;
-    hipLaunchKernelGGL((conv_ksplit_kernel<T, TO, TAPS, TCO, TPOS, DEPTH>), dim3(a.nblk), dim3(256), lds, st, a);
+    if constexpr (TAPS != 1 && sizeof(T) == sizeof(TO)) {
+        if (op.flags & ADK_FLAG_FUSE_GN) {
+            const void* fn = reinterpret_cast<const void*>(&conv_ksplit_kernel<T, TO, TAPS, TCO, TPOS, DEPTH, true>);
+            static int cap[64];
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ADK_ELAUNCH;
+            if (!cap[dev]) {
+                int per_cu = 0, cus = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess) return ADK_ELAUNCH;
+                if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return ADK_ELAUNCH;
+                const int lb = TCO * TPOS >= 4 ? 1 : 2;      // __launch_bounds__
+                if (per_cu > lb) per_cu = lb;
+                if (per_cu < 1 || cus < 1) return ADK_ELAUNCH;
+                cap[dev] = per_cu * cus;
+            }
+            if (a.npb > cap[dev]) return ADK_EINVAL;
+            a.gn_cap = (unsigned)cap[dev];
+            hipLaunchKernelGGL((conv_ksplit_kernel<T, TO, TAPS, TCO, TPOS, DEPTH, true>), dim3(a.nblk), dim3(256), lds, st, a);
+            return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
+        }
+    }
+    hipLaunchKernelGGL((conv_ksplit_kernel<T, TO, TAPS, TCO, TPOS, DEPTH, false>), dim3(a.nblk), dim3(256), lds, st, a);
     return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
 }
 

@@ -31,7 +31,7 @@ void conv_fill_args(const adk_op& op, int BN, int BM, ConvArgs& a)
     a.shift = (op.flags & ADK_FLAG_CAUSAL) ? (op.taps - 1) * a.dil : (op.taps / 2) * a.dil;
     a.elu = (op.flags & ADK_FLAG_ELU) ? 1 : 0;
     a.gamma = a.beta = nullptr; a.gn_ws = nullptr; a.gn_epoch = nullptr; a.gn_err = nullptr;
-    a.gn_slot = 0; a.gn_ticket = nullptr; a.npb = a.tps * a.ncot; a.gelu = 0; a.eps = 0.f; a.gn_count = 1.0;
+    a.gn_slot = a.gn_delay = a.gn_cap = 0; a.gn_ticket = nullptr; a.npb = a.tps * a.ncot; a.gelu = 0; a.eps = 0.f; a.gn_count = 1.0;
     if (op.flags & ADK_FLAG_FUSE_GN) {
         a.gamma = op.gamma; a.beta = op.beta;
         a.gn_ws = reinterpret_cast<unsigned long long*>(op.aux1);
@@ -56,7 +56,7 @@ int conv_gn_check(const adk_op& op, const char** why)
     if (!why) why = &dummy;
     *why = none;
     const ConvTile t = conv_tile(op);
-    if (t.ksplit || t.bn != 128) { *why = "only the pipelined 128-channel tiles (L > 128, Cout > 32)"; return 0; }
+    if (!t.ksplit && t.bn != 128) { *why = "not for the narrow-output kernel (Cout <= 32 above the short levels)"; return 0; }
     if (op.taps != 3 && op.taps != 5 && op.taps != 7) { *why = "taps must be 3, 5 or 7"; return 0; }
     if ((op.flags & (ADK_FLAG_CAUSAL | ADK_FLAG_ELU | ADK_FLAG_GROUP_STATS | ADK_FLAG_OUT_F32)) || op.i0 > 1) {
         *why = "not with causal / dilated / ELU / group-statistics / f32-output convs"; return 0;
@@ -119,8 +119,8 @@ static int launch_taps(const adk_op& op, hipStream_t st)
 int launch_conv(const adk_op& op, hipStream_t st)
 {
     const ConvTile ct = conv_tile(op);
-    if (op.flags & ADK_FLAG_FUSE_GN) return launch_conv_gn(op, st);
     if (ct.ksplit) return launch_conv_ksplit(op, st);
+    if (op.flags & ADK_FLAG_FUSE_GN) return launch_conv_gn(op, st);
     if ((op.flags & (ADK_FLAG_CAUSAL | ADK_FLAG_ELU | ADK_FLAG_GROUP_STATS)) || op.i0 > 1) return launch_conv_ext(op, st);
     if (op.dtype == ADK_F32) return launch_taps<float, float>(op, st);
     if (op.dtype == ADK_F16)

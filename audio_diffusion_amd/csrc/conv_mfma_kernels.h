@@ -5,7 +5,7 @@
 #include "conv_common.h"
 
 #ifdef ADK_ABL_TS       // experiment builds only: per-block timestamps (make exp-ts; tools/conv_block_timeline.py)
-__device__ unsigned long long g_adk_ts[16384 * 8];
+__device__ unsigned long long g_adk_ts[16384 * 9];     // [block][8] stamps, then [block] start of the K-loop prologue (fused kernel)
 #define ADK_TS(SLOT_) if (threadIdx.x == 0 && blockIdx.x < 16384) g_adk_ts[blockIdx.x * 8 + (SLOT_)] = wall_clock64();
 #else
 #define ADK_TS(SLOT_)
@@ -355,7 +355,12 @@ __device__ __forceinline__ ConvTileId conv_tile_mainloop(const ConvArgs& a, cons
     constexpr int XBYTES = XI * NW * 1024, WBYTES = BN * 64;
     typedef typename Mma<T>::Frag Frag;
 
+#ifdef ADK_ABL_TS_GN
+    ADK_TS(3 + 0 * 0)   /* overwritten below by the hardware id; the fused kernel stamps slot 0 before its ticket */
+    if (threadIdx.x == 0 && blockIdx.x < 16384) g_adk_ts[16384 * 8 + blockIdx.x] = wall_clock64();
+#else
     ADK_TS(0)
+#endif
 #ifdef ADK_ABL_TS
     if (threadIdx.x == 0 && blockIdx.x < 16384) {
         unsigned hwid, xcc;

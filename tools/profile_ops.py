@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--T", type=int, default=65536)
     ap.add_argument("--model", default="uncond", help="uncond (config 2) | 3a (long context) | k-audio (k_audio_uncond_long_1.json, B=4, 32 x 32768)")
+    ap.add_argument("--no-fuse-gn", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "fp32": torch.float32}[a.dtype]
@@ -44,6 +45,7 @@ def main():
             m = A.DiffusionAttnUnet1D().to(dev).eval()
         else:
             m = A.DiffusionAttnUnet1D(n_attn_layers=4).to(dev).eval()
+        m.fuse_gn = not a.no_fuse_gn
         plan = m.plan_for(a.batch, a.T, dtype, dev)
         x = torch.randn(a.batch, 2, a.T, device=dev)
         t = torch.ones(a.batch, device=dev)
@@ -68,7 +70,8 @@ def main():
     for i, meta in enumerate(plan.meta):
         k = NAMES.get(meta["kind"], str(meta["kind"]))
         if meta["kind"] == 1:
-            key = (k, f"k{meta['taps']}", f"L{meta['L']}", f"{meta['cin']}->{meta['cout']}", f"tile{meta['cotile']}x{meta['postile']}")
+            fz = ("+gn" + ("+res" if plan.ops[i].residual else "")) if meta.get("fused_gn") else ""
+            key = (k, f"k{meta['taps']}{fz}", f"L{meta['L']}", f"{meta['cin']}->{meta['cout']}", f"tile{meta['cotile']}x{meta['postile']}")
         else:
             key = (k, f"L{meta.get('L', 0)}", f"C{meta.get('c', 0)}")
         e = agg[key]
@@ -77,7 +80,7 @@ def main():
     print(f"total {total:.3f} ms over {plan.n_ops} ops (event-timed, includes launch gaps)")
     bykind = defaultdict(float)
     for key, e in agg.items():
-        bykind[key[0] + (key[1] if key[0] == "conv" else "")] += e[1]
+        bykind[key[0] + (key[1][:2] if key[0] == "conv" else "")] += e[1]
     for k, v in sorted(bykind.items(), key=lambda kv: -kv[1]):
         print(f"  {k:12s} {v:8.3f} ms  {100 * v / total:5.1f}%")
     print("-- detail (sorted by time)")

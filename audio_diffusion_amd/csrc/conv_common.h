@@ -17,7 +17,7 @@ struct ConvArgs {
     const unsigned* gn_epoch;    // [0] = per-forward epoch base (advanced by an earlier kernel); the tag also carries gn_slot
     unsigned* gn_err;            // set to a non-zero code when a bounded wait runs out
     unsigned* gn_ticket;         // this op's tile counter (grows by nblk per forward)
-    unsigned gn_slot, gn_delay, gn_cap;   // gn_delay: start offset of every other sample of the first wave (10 ns ticks)
+    unsigned gn_slot, gn_cap;             // gn_cap: resident block slots of the kernel on this device (0xffffffff: experiment, no tickets)
     int npb, gelu;               // tiles per sample (= tps * ncot)
     float eps; double gn_count;  // Cout * L
 };

@@ -35,7 +35,7 @@ OP_DDIM_UPDATE, OP_STEP_ADVANCE, OP_AUDIO_TO_INT16, OP_SPACE_TO_DEPTH, OP_DEPTH_
 OP_LINEAR, OP_FOURIER = 16, 17
 
 FLAG_GELU, FLAG_OUT_F32, FLAG_NOISE, FLAG_ADA, FLAG_LOG, FLAG_NO_EMBED, FLAG_GROUP_STATS, FLAG_WT = 1, 2, 4, 8, 16, 32, 64, 128
-FLAG_CAUSAL, FLAG_ELU, FLAG_FUSE_GN = 256, 512, 1024
+FLAG_CAUSAL, FLAG_ELU, FLAG_FUSE_GN, FLAG_SKIP_CONV = 256, 512, 1024, 2048
 
 
 class AdkOp(C.Structure):
@@ -50,12 +50,12 @@ class AdkOp(C.Structure):
         ("y", C.c_void_p),
         ("gamma", C.c_void_p), ("beta", C.c_void_p), ("partials_in", C.c_void_p),
         ("partials_out", C.c_void_p),
-        ("aux0", C.c_void_p), ("aux1", C.c_void_p),
+        ("aux0", C.c_void_p), ("aux1", C.c_void_p), ("w2", C.c_void_p),
     ]
 
 
 EXPORTS = [
-    "adk_version", "adk_last_error", "adk_run_plan", "adk_validate_plan", "adk_partials_count", "adk_conv_postile", "adk_conv_cotile_used", "adk_conv_cotile",
+    "adk_version", "adk_last_error", "adk_sizeof_op", "adk_run_plan", "adk_validate_plan", "adk_partials_count", "adk_conv_postile", "adk_conv_cotile_used", "adk_conv_cotile",
     "adk_conv1d", "adk_gn_apply", "adk_gn_stats", "adk_fir_down2", "adk_fir_up2", "adk_attn1d",
     "adk_pack_input", "adk_pack_input_cond", "adk_unpack_output", "adk_pqmf_analysis", "adk_pqmf_synthesis",
     "adk_ddim_update", "adk_step_advance", "adk_audio_to_int16", "adk_space_to_depth", "adk_depth_to_space",

@@ -93,6 +93,12 @@ static int validate(const adk_op& o)
             REQUIRE(o.i1 >= 0 && o.i1 < 4095, "conv1d + GroupNorm fusion: slot %d outside [0, 4095)", o.i1);
             REQUIRE(!o.partials_out || o.residual, "conv1d + GroupNorm fusion: output statistics are built for the residual form");
         }
+        if (o.flags & ADK_FLAG_SKIP_CONV) {
+            REQUIRE(o.flags & ADK_FLAG_FUSE_GN, "conv1d: the folded skip conv belongs to the conv + GroupNorm fusion");
+            REQUIRE(o.L > 128, "conv1d: the folded skip conv is built for the pipelined kernel (L > 128)");
+            REQUIRE(o.residual && o.w2, "conv1d + folded skip conv: needs the block input (residual) and the skip weights (w2)");
+            REQUIRE(o.i2 >= cb && o.i2 % cb == 0, "conv1d + folded skip conv: input channels i2=%d not a multiple of %d", o.i2, cb);
+        }
         return ADK_OK;
     }
     case ADK_OP_GN_APPLY:
@@ -274,6 +280,7 @@ int adk_conv_postile(const adk_op* op) { return (op && op->kind == ADK_OP_CONV) 
 
 int adk_conv_cotile(int dtype, int Cout, int L) { (void)dtype; (void)L; return conv_cotile(Cout); }
 
+int adk_sizeof_op(void) { return (int)sizeof(adk_op); }
 int adk_conv_gn_fusable(const adk_op* op) { return (op && op->kind == ADK_OP_CONV) ? conv_gn_check(*op, nullptr) : 0; }
 
 static adk_op zero_op(int kind, int dtype)

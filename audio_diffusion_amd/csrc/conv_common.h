@@ -20,6 +20,7 @@ struct ConvArgs {
     unsigned gn_slot, gn_cap;             // gn_cap: resident block slots of the kernel on this device (0xffffffff: experiment, no tickets)
     int npb, gelu;               // tiles per sample (= tps * ncot)
     float eps; double gn_count;  // Cout * L
+    const void* w2; int nchunks2;   // ADK_FLAG_SKIP_CONV: packed 1x1 weights of the folded skip conv, channel chunks of its input (= residual)
 };
 
 template <typename T> struct Mma;

@@ -42,6 +42,8 @@ void conv_fill_args(const adk_op& op, int BN, int BM, ConvArgs& a)
         a.gelu = (op.flags & ADK_FLAG_GELU) ? 1 : 0;
         a.eps = op.f0; a.gn_count = (double)op.Cout * (double)op.L;
     }
+    a.w2 = nullptr; a.nchunks2 = 0;
+    if (op.flags & ADK_FLAG_SKIP_CONV) { a.w2 = op.w2; a.nchunks2 = op.i2 / CB; }
 }
 
 // ADK_FLAG_FUSE_GN: which conv ops the fused conv + GroupNorm kernel takes (host-only; the launch re-checks the

@@ -334,7 +334,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_visible() {
 // epilogue).  `lid` = logical tile id, co tile fastest, then position tile, then sample.
 struct ConvTileId { int b, t, cot, cobase, l0; };
 
-template <bool EXT, typename T, int TAPS, int WCO, int WPOS, int TCO, int TPOS, int DIL>
+// KEEP = true: the accumulators are NOT reset to the bias - the K loop adds onto what they hold (the 1x1 skip conv of a
+// ResidualBlock folded into the fused conv + GroupNorm kernel as extra single-tap phases, conv_mfma_gn.inc).
+template <bool EXT, typename T, int TAPS, int WCO, int WPOS, int TCO, int TPOS, int DIL, bool KEEP = false>
 __device__ __forceinline__ ConvTileId conv_tile_mainloop(const ConvArgs& a, const unsigned lid, unsigned char* smem,
                                                          f32x16 (&acc)[TCO][TPOS], const int tid)
 {
@@ -392,7 +394,7 @@ __device__ __forceinline__ ConvTileId conv_tile_mainloop(const ConvArgs& a, cons
     const int total = a.nchunks * TAPS;
 
     float4 bv[TCO][4];
-    conv_bias_fetch<TCO>(a, bv, cobase, wco, h);           // bias loads go out first (see conv_bias_fetch)
+    if constexpr (!KEEP) conv_bias_fetch<TCO>(a, bv, cobase, wco, h);           // bias loads go out first (see conv_bias_fetch)
 
     // per-lane source offsets (bytes) inside a plane / a weight chunk, fixed for the whole kernel
     unsigned xsrc[XI], wsrc[WI];
@@ -447,8 +449,8 @@ __device__ __forceinline__ ConvTileId conv_tile_mainloop(const ConvArgs& a, cons
         if (u < total) issue_unit(u);
     {
         constexpr int n0 = []() { int n = 0; for (int u = 1; u < K; ++u) n += WI + (u % TAPS == 0 ? XI : 0); return n; }();
-        if (total >= K) { wait_vmcnt_visible<n0>(); conv_acc_set<TCO, TPOS>(acc, bv); }
-        else { wait_vmcnt_visible<0>(); conv_acc_set<TCO, TPOS>(acc, bv); }
+        if (total >= K) wait_vmcnt_visible<n0>(); else wait_vmcnt_visible<0>();
+        if constexpr (!KEEP) conv_acc_set<TCO, TPOS>(acc, bv);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         ADK_LOAD_FRAGS(a0, b0, ws + wfrag, xs + xfrag, wsw, 0)

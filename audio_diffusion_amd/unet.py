@@ -89,6 +89,7 @@ class _Plan:
         # conv + GroupNorm fusion (ADK_FLAG_FUSE_GN, include/adk.h): state words {epoch, error, counters[4095]} and the
         # statistics-exchange workspace, both allocated first and never released (the arena starts zeroed)
         self.fuse_gn = bool(getattr(model, "fuse_gn", True))
+        self.fold_skip = bool(getattr(model, "fold_skip", True))      # 1x1 skip convs inside the fused conv + GroupNorm launch
         self._gn_state = self._gn_ws = None
         self._gn_slots = 0
         self._build()
@@ -183,9 +184,11 @@ class _Plan:
         return bool(self.lib.adk_conv_gn_fusable(ctypes.byref(op)))
 
     def conv(self, x, key, w, bias, Cout, out=None, residual=None, stats=False, out_f32=False, gstats=False,
-             dilation=1, causal=False, elu=False, gn=None):
+             dilation=1, causal=False, elu=False, gn=None, skip=None):
         """``gn = (key, gamma, beta, gelu)``: GroupNorm(1, Cout) [+ GELU] fused into the conv's epilogue; ``residual``
-        is then added AFTER norm + activation and ``stats`` are those of the final output."""
+        is then added AFTER norm + activation and ``stats`` are those of the final output.  ``skip = (x_in, key, w)``
+        (with ``gn``): ResidualBlock's 1x1 skip conv (reference blocks/blocks.py:68) runs inside the same launch on the
+        block input ``x_in`` instead of a ``residual`` tensor."""
         taps = w.shape[2]
         bn = self.lib.adk_conv_cotile(self.adk_dtype, Cout, x.L)
         cout_pad = _ceil_to(Cout, bn)
@@ -214,6 +217,14 @@ class _Plan:
             ptrs["aux0"], ptrs["aux1"] = ("arena", state.off), ("arena", ws.off)
             extra = dict(i1=self._gn_slots, f0=GN_EPS)
             self._gn_slots += 1
+            if skip is not None:
+                assert residual is None
+                xs, skey, sw = skip
+                cs_alloc = _ceil_to(xs.C, 16 if xs.f32 else 32)
+                flags |= _lib.FLAG_SKIP_CONV
+                ptrs["residual"] = ("arena", xs.off)
+                ptrs["w2"] = ("abs", self._packed_conv(skey, sw, cs_alloc, cout_pad))
+                extra["i2"] = cs_alloc
         op = self._emit(_lib.OP_CONV, ptrs, flags=flags, L=x.L, Cin=cin_alloc, Cout=Cout, CoutPad=cout_pad, taps=taps,
                         i0=dilation if dilation > 1 else 0, **extra)
         self.meta[-1].update(taps=taps, L=x.L, cin=w.shape[1], cout=Cout, cotile=self.lib.adk_conv_cotile_used(ctypes.byref(op)),
@@ -222,7 +233,10 @@ class _Plan:
                              bytes=float(self.B) * x.L * (cin_alloc * (4 if x.f32 else 2) + Cout * (4 if y.f32 else 2))
                              + float(cin_alloc) * cout_pad * taps * (4 if x.f32 else 2)
                              + (float(self.B) * x.L * Cout * (4 if y.f32 else 2) if (gn is not None and residual is not None) else 0.0),
-                             fused_gn=gn is not None)
+                             fused_gn=gn is not None, fused_skip=skip is not None)
+        if skip is not None:
+            self.meta[-1]["flops"] += 2.0 * skip[2].shape[1] * Cout * x.L * self.B
+            self.meta[-1]["bytes"] += float(self.B) * x.L * extra["i2"] * (4 if x.f32 else 2) + float(extra["i2"]) * cout_pad * (4 if x.f32 else 2)
         part = None
         if stats:
             n = self.lib.adk_partials_count(ctypes.byref(op))
@@ -323,13 +337,15 @@ class _Plan:
             return y, None
         g2 = blk.main[4]
         if self.gn_fusable(h1, c2.weight, blk.c_out):        # conv -> GroupNorm -> GELU -> + skip(x) as one launch
+            fold = has_skip and self.fold_skip and h1.L > 128 and x.f32 == h1.f32     # pipelined kernel: skip conv inside too
             r = x
-            if has_skip:
+            if has_skip and not fold:
                 r, _ = self.conv(x, key + "skip", blk.skip.weight, None, blk.c_out)
-            y, pout = self.conv(h1, key + "main.3", c2.weight, c2.bias, blk.c_out, out=out, residual=r, stats=stats,
-                                gn=(key + "main.4", g2.weight, g2.bias, True))
+            y, pout = self.conv(h1, key + "main.3", c2.weight, c2.bias, blk.c_out, out=out, residual=None if fold else r,
+                                stats=stats, gn=(key + "main.4", g2.weight, g2.bias, True),
+                                skip=(x, key + "skip", blk.skip.weight) if fold else None)
             self.free(h1)
-            if has_skip:
+            if has_skip and not fold:
                 self.free(r)
             return y, pout
         raw2, p2 = self.conv(h1, key + "main.3", c2.weight, c2.bias, blk.c_out, stats=True)

@@ -92,6 +92,12 @@ enum {
                                    waited in vain for its sample's other tiles or the counters are out of step.
                                    Only where adk_conv_gn_fusable(). */
 
+#define ADK_FLAG_SKIP_CONV 2048u /* CONV with ADK_FLAG_FUSE_GN: ResidualBlock's 1x1 skip conv (blocks/blocks.py:68, added at :14-15)
+                                   folded into the launch: `residual` is then the BLOCK INPUT, CPL [B, i2, L] (i2 = its channel
+                                   count, a multiple of CB), w2 = the skip's packed weights [i2/CB][1][CoutPad][CB] (no bias), and
+                                   y = [GELU](GroupNorm(conv(x))) + conv1x1(residual, w2), summed in the fp32 accumulators.
+                                   Pipelined kernel only (L > 128). */
+
 /* One flat descriptor for every op kind; unused fields are 0/NULL.  Field use per kind is
  * documented at the matching adk_* entry point below (same names). */
 typedef struct adk_op {
@@ -109,10 +115,12 @@ typedef struct adk_op {
     float *partials_out;
     const void *aux0;
     void *aux1;
+    const void *w2;              /* CONV + ADK_FLAG_SKIP_CONV: second weight tensor                 */
 } adk_op;
 
 int adk_version(void);
 const char *adk_last_error(void);
+int adk_sizeof_op(void);        /* sizeof(adk_op) of this build: lets a binding check its mirror of the struct */
 
 /* Validate and launch n ops in order on `stream` (one host call per denoiser forward). */
 int adk_run_plan(const adk_op *ops, int n, void *stream);

@@ -346,6 +346,14 @@ FUSED_CASES = [
     (16, 128, 1024, 512, 5, True, False),   # concat input, 64x64 tiles (one block per CU)
     (3, 40, 64, 96, 3, True, True),         # ragged 64-position tile, Cout not a tile multiple
     (40, 64, 128, 512, 5, True, False),     # 640 blocks > resident slots: tiles handed out by ticket
+    # residual = an int: ResidualBlock's 1x1 skip conv over that many input channels, folded into the launch
+    # (ADK_FLAG_SKIP_CONV, pipelined kernel)
+    (3, 300, 64, 128, 5, 64, False),        # 128x128 tiles
+    (2, 200, 32, 96, 5, 32, True),          # 128x64 tile, pad channels, output statistics
+    (2, 65536, 32, 128, 5, 64, False),      # 128x256 tiles, 256 per sample
+    (5, 4100, 64, 256, 3, 128, True),       # two co tiles, 3 taps, more skip chunks than main chunks
+    (2, 1000, 96, 160, 7, 64, False),       # 7 taps
+    (20, 4096, 128, 128, 5, 256, False),    # the up path's 2c -> c block: 8 skip chunks
 ]
 
 
@@ -365,10 +373,14 @@ def test_conv_groupnorm_gelu_fused(env, dt, case):
     w = torch.randn(Cout, Cin, taps, generator=g) / (Cin * taps) ** 0.5
     bias = torch.randn(Cout, generator=g) * 0.3
     gamma, beta = torch.randn(Cout, generator=g) * 0.5 + 1.0, torch.randn(Cout, generator=g) * 0.2
-    r = torch.randn(B, Cout, L, generator=g) if res else None
+    skip_c = res if (res is not True and res is not False) else 0
+    r = torch.randn(B, skip_c or Cout, L, generator=g) if res else None
+    w2 = torch.randn(Cout, skip_c, 1, generator=g) / skip_c ** 0.5 if skip_c else None
     xq, wq = quant(x, dtype), quant(w, dtype)
     ref = F.gelu(F.group_norm(F.conv1d(xq, wq, bias, padding=P), 1, gamma, beta, 1e-5))
-    if res:
+    if skip_c:
+        ref = ref + F.conv1d(quant(r, dtype), quant(w2, dtype))
+    elif res:
         ref = ref + quant(r, dtype)
     bn = lib.adk_conv_cotile(adk, Cout, L)
     cout_pad = (Cout + bn - 1) // bn * bn
@@ -390,6 +402,10 @@ def test_conv_groupnorm_gelu_fused(env, dt, case):
     pout = torch.zeros(B, npart, 2, device=dev) if stats else None
     op.x, op.w, op.bias, op.gamma, op.beta = xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), gd.data_ptr(), btd.data_ptr()
     op.residual = rd.data_ptr() if res else None
+    if skip_c:
+        w2d = pack_w(w2, skip_c, cout_pad, cb, dtype, dev)
+        op.flags |= _lib.FLAG_SKIP_CONV
+        op.w2, op.i2 = w2d.data_ptr(), skip_c
     op.partials_out = pout.data_ptr() if stats else None
     op.aux0, op.aux1 = state.data_ptr(), ws.data_ptr()
     outs = []

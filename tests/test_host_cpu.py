@@ -30,8 +30,9 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_adk_op_struct_size_matches_c():
-    # 14 int32 + 2 float = 64 bytes, then 11 pointers
-    assert ctypes.sizeof(_lib.AdkOp) == 64 + 11 * 8
+    # 14 int32 + 2 float = 64 bytes, then 12 pointers; and what the library itself was compiled with
+    assert ctypes.sizeof(_lib.AdkOp) == 64 + 12 * 8
+    assert _lib.load().adk_sizeof_op() == ctypes.sizeof(_lib.AdkOp)
 
 
 def test_validation_messages_without_gpu():
@@ -68,7 +69,15 @@ def test_full_model_init_matches_reference_digest():
     # a ResConvBlock but the last block's, which has no norm), the 36 attention norms stay passes of their own
     fused = sum(1 for i in range(plan.n_ops) if plan.ops[i].kind == _lib.OP_CONV and plan.ops[i].flags & _lib.FLAG_FUSE_GN)
     assert fused == 167 and kinds.count(_lib.OP_GN_APPLY) == 203 - fused
-    assert kinds.count(_lib.OP_CONV) == 259          # 168 k=5 + 19 skips + 72 qkv/out projections
+    # 168 k=5 + 72 qkv/out projections + 5 skips: the other 14 skip convs (every one above the k-split levels but the
+    # last block's) run inside the fused launch of their block's second conv (ADK_FLAG_SKIP_CONV)
+    folded = sum(1 for i in range(plan.n_ops) if plan.ops[i].kind == _lib.OP_CONV and plan.ops[i].flags & _lib.FLAG_SKIP_CONV)
+    assert folded == 14 and kinds.count(_lib.OP_CONV) == 259 - folded
+    m.fold_skip = False
+    nofold = _Plan(m, 1, 65536, torch.bfloat16, torch.device("cpu"))
+    nofold.validate()
+    assert [nofold.ops[i].kind for i in range(nofold.n_ops)].count(_lib.OP_CONV) == 259
+    m.fold_skip = True
     assert len({plan.ops[i].i1 for i in range(plan.n_ops) if plan.ops[i].flags & _lib.FLAG_FUSE_GN
                 and plan.ops[i].kind == _lib.OP_CONV}) == fused          # one ticket counter per fused conv
     m.fuse_gn = False                                 # the unfused plan stays available (A/B, and > 512 tiles per sample)

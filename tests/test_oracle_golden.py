@@ -161,9 +161,13 @@ def test_crash_schedule_vs_reference_fixture():
     for steps in (5, 6, 10, 100, 250):
         want = torch.from_numpy(g[f"crash/t{steps}"])
         t = torch.linspace(1, 0, steps + 1)[:-1]
-        assert torch.equal(S.crash_schedule(t), want)
-        assert torch.equal(A.get_crash_schedule(t), want)                      # the product's host function
-        assert torch.equal(A.step_coefficients(steps, 0, A.get_crash_schedule)[:, 0], want)
+        # sin / atan2 of the host's libm: the last bit depends on the CPU the fixture was recorded on (2 ulp allowed);
+        # the oracle and the product's host function must agree with each other exactly on any one host
+        close = lambda a: torch.allclose(a, want, rtol=0, atol=2.4e-7)
+        assert close(S.crash_schedule(t))
+        assert close(A.get_crash_schedule(t))                                  # the product's host function
+        assert torch.equal(A.get_crash_schedule(t), S.crash_schedule(t))
+        assert torch.equal(A.step_coefficients(steps, 0, A.get_crash_schedule)[:, 0], A.get_crash_schedule(t))
 
 
 def test_crash_sampler_and_diffae_oracle_vs_reference_fixture():

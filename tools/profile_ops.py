@@ -70,7 +70,7 @@ def main():
     for i, meta in enumerate(plan.meta):
         k = NAMES.get(meta["kind"], str(meta["kind"]))
         if meta["kind"] == 1:
-            fz = ("+gn" + ("+res" if plan.ops[i].residual else "")) if meta.get("fused_gn") else ""
+            fz = ("+gn" + ("+skip" if meta.get("fused_skip") else ("+res" if plan.ops[i].residual else ""))) if meta.get("fused_gn") else ""
             key = (k, f"k{meta['taps']}{fz}", f"L{meta['L']}", f"{meta['cin']}->{meta['cout']}", f"tile{meta['cotile']}x{meta['postile']}")
         else:
             key = (k, f"L{meta.get('L', 0)}", f"C{meta.get('c', 0)}")

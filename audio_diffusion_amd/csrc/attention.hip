@@ -17,7 +17,8 @@
 //                          (rows 8s..8s+7 = k-step s); A = V^T gathered by ds_read_b64_tr_b16
 //                          in the same (permuted) key order
 //   so neither P nor the [s,s] scores ever touch LDS, and the rescale factor is a per-lane scalar.
-// f32: attn_kernel (v1): one query row per lane, K/V tiles in LDS as fp32, exact fp32 math (rtol 1e-4).
+// f32: attn_mfma_f32_kernel (s >= 128: the same structure on the exact-fp32 matrix instruction) and attn_kernel (short
+// sequences: one query row per lane, K/V tiles in LDS as fp32, exact fp32 VALU math); both hold rtol 1e-4.
 #include "adk_common.h"
 
 struct AttnArgs {
@@ -356,6 +357,198 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnMfmaArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// f32, long sequences: attn_mfma_f32_kernel.  The same "query on the lane" flash structure as attn_mfma_kernel on
+// the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32 (an fp32 FMA chain: parity path, rtol 1e-4):
+//     S^T = K Q^T     one MFMA per pair of head-dim elements; lane (row, h) supplies element 16 (2 t + h) + s of its row
+//                     at step (t, s), i.e. half h of the wave reads plane 2 t + h of the head (a 64-byte row = 16 floats),
+//                     for K and Q alike (the order of the head-dim sum is free)
+//     O^T += V^T P^T  one MFMA per pair of keys: the fp32 score register st[r] (key (r & 3) + 8 (r >> 2) + 4 h) IS the B
+//                     operand, A = V[that key][d = lane & 31] read from a wave-private LDS tile ([key][D + 8] floats:
+//                     the two half-waves read rows 4 apart, the 8-float pad puts them on different banks)
+// No block barrier; the VALU attn_kernel above stays for short sequences (s < 128), where one wave per 64 queries of a
+// head leaves nothing to tile.
+template <int TQ, int D>
+__global__ __launch_bounds__(256, 2) void attn_mfma_f32_kernel(const AttnMfmaArgs a)
+{
+    constexpr int PPH = D / 16;                 // 64-byte planes per head
+    constexpr int NP = PPH / 2;                 // planes per half-wave
+    constexpr int DP = D / 32;                  // 32-wide output blocks of the head dim
+    constexpr int VSTR = D + 8;                 // floats per key row of the LDS V tile
+    constexpr int VBUF = 32 * VSTR * 4;         // bytes per tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= a.nitems) return;                           // wave-uniform; no block barrier in this kernel
+    const int qt = item % a.ntq, rest = item / a.ntq, hd = rest % a.heads, b = rest / a.heads;
+    const long long srow = (long long)b * a.Lp + a.P;
+    const int last = a.L - 1;
+    const long long pstride = a.M * 64;
+    const unsigned char* qg = reinterpret_cast<const unsigned char*>(a.qkv) + ((long long)hd * PPH * a.M + srow) * 64;
+    const unsigned char* kg = qg + (long long)a.heads * PPH * pstride;
+    const unsigned char* vg = kg + (long long)a.heads * PPH * pstride;
+    float* vlds = reinterpret_cast<float*>(smem + wave * (2 * VBUF));
+
+    // Q: lane (q = l31, h) holds planes 2 t + h of its query row
+    float4 qf[TQ][NP][4];
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) {
+        int q = (qt * TQ + u) * 32 + l31;
+        q = q > last ? last : q;
+#pragma unroll
+        for (int t = 0; t < NP; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                qf[u][t][e] = *reinterpret_cast<const float4*>(qg + (2 * t + h) * pstride + (long long)q * 64 + e * 16);
+    }
+
+    struct KvTile { float4 k[NP][4]; float4 v[PPH][2]; };
+    auto fetch_tile = [&](int kt) -> KvTile {
+        KvTile r;
+        int key = kt * 32 + l31;
+        key = key > last ? last : key;                      // keys past the sample are masked below
+        int vk0 = kt * 32 + (lane >> 2), vk1 = vk0 + 16;
+        vk0 = vk0 > last ? last : vk0;
+        vk1 = vk1 > last ? last : vk1;
+#pragma unroll
+        for (int t = 0; t < NP; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                r.k[t][e] = *reinterpret_cast<const float4*>(kg + (2 * t + h) * pstride + (long long)key * 64 + e * 16);
+#pragma unroll
+        for (int p = 0; p < PPH; ++p) {                     // whole rows: lane = piece (lane & 3) of rows (lane >> 2), + 16
+            r.v[p][0] = *reinterpret_cast<const float4*>(vg + p * pstride + (long long)vk0 * 64 + (lane & 3) * 16);
+            r.v[p][1] = *reinterpret_cast<const float4*>(vg + p * pstride + (long long)vk1 * 64 + (lane & 3) * 16);
+        }
+        return r;
+    };
+
+    f32x16 o[TQ][DP];
+    float mrun[TQ], lrun[TQ];
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) {
+        mrun[u] = -INFINITY; lrun[u] = 0.f;
+#pragma unroll
+        for (int p = 0; p < DP; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[u][p][r] = 0.f;
+    }
+    const float c = D == 32 ? 0.25503486f : 0.18033688f;    // log2(e) * d^-1/2  (q and k each scaled by d^-1/4)
+
+    const int nt = (a.L + 31) >> 5;
+    KvTile cur = fetch_tile(0);
+    for (int kt = 0; kt < nt; ++kt) {
+        float* vb = vlds + (kt & 1) * (VBUF / 4);
+        float4 kf[NP][4];
+#pragma unroll
+        for (int p = 0; p < PPH; ++p) {
+            *reinterpret_cast<float4*>(vb + (lane >> 2) * VSTR + p * 16 + (lane & 3) * 4) = cur.v[p][0];
+            *reinterpret_cast<float4*>(vb + ((lane >> 2) + 16) * VSTR + p * 16 + (lane & 3) * 4) = cur.v[p][1];
+        }
+#pragma unroll
+        for (int t = 0; t < NP; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) kf[t][e] = cur.k[t][e];
+        if (kt + 1 < nt) cur = fetch_tile(kt + 1);
+        const bool ragged = (kt + 1) * 32 > a.L;
+
+#pragma unroll
+        for (int u = 0; u < TQ; ++u) {
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < NP; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t][e].x, qf[u][t][e].x, st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t][e].y, qf[u][t][e].y, st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t][e].z, qf[u][t][e].z, st, 0, 0, 0);
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t][e].w, qf[u][t][e].w, st, 0, 0, 0);
+                }
+            if (ragged) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h > last) st[r] = -INFINITY;
+            }
+            float mx = st[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(mrun[u], mx * c);
+            const float alpha = __builtin_amdgcn_exp2f(mrun[u] - mnew);
+            mrun[u] = mnew;
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                st[r] = __builtin_amdgcn_exp2f(st[r] * c - mnew);
+                ps += st[r];
+            }
+            lrun[u] = lrun[u] * alpha + ps;
+#pragma unroll
+            for (int p = 0; p < DP; ++p) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[u][p][r] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float vv = vb[((r & 3) + 8 * (r >> 2) + 4 * h) * VSTR + 32 * p + l31];
+                    o[u][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, st[r], o[u][p], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: o[u][p][r] = O[query l31][d = 32 p + (r & 3) + 8 (r >> 2) + 4 h] (unnormalised) ----
+    unsigned char* yb = reinterpret_cast<unsigned char*>(a.y) + ((long long)hd * PPH * a.M + srow) * 64;
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) {
+        const float ltot = lrun[u] + __shfl_xor(lrun[u], 32, 64);
+        const float inv = 1.0f / ltot;
+        const int q = (qt * TQ + u) * 32 + l31;
+        if (q <= last) {
+#pragma unroll
+            for (int p = 0; p < DP; ++p)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = 32 * p + 8 * g + 4 * h;               // 4 consecutive head-dim elements
+                    *reinterpret_cast<float4*>(yb + (d0 >> 4) * pstride + (long long)q * 64 + (d0 & 15) * 4) =
+                        make_float4(o[u][p][4 * g] * inv, o[u][p][4 * g + 1] * inv, o[u][p][4 * g + 2] * inv, o[u][p][4 * g + 3] * inv);
+                }
+        }
+    }
+    if (qt == 0 || qt == a.ntq - 1) {                       // halo rows of this head's planes
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < a.P * 4) {
+            const int row = lane >> 2, pc = lane & 3;
+#pragma unroll
+            for (int p = 0; p < PPH; ++p) {
+                if (qt == 0) *reinterpret_cast<float4*>(yb + p * pstride + (long long)(row - a.P) * 64 + pc * 16) = z;
+                if (qt == a.ntq - 1) *reinterpret_cast<float4*>(yb + p * pstride + (long long)(a.L + row) * 64 + pc * 16) = z;
+            }
+        }
+    }
+}
+
+template <int TQ, int D>
+static int launch_attn_mfma_f32(const adk_op& op, hipStream_t st)
+{
+    AttnMfmaArgs a;
+    a.qkv = op.x; a.y = op.y;
+    a.B = op.B; a.L = op.L; a.P = op.P; a.Lp = op.L + 2 * op.P; a.M = (long long)op.B * a.Lp;
+    a.heads = op.Cin / D; a.ntq = (op.L + 32 * TQ - 1) / (32 * TQ);
+    a.nitems = op.B * a.heads * a.ntq;
+    const size_t lds = (size_t)4 * 2 * 32 * (D + 8) * 4;
+    static bool attr_set = false;             // d = 64: 72 KiB of dynamic LDS needs the opt-in, once per kernel
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_f32_kernel<TQ, D>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ADK_ELAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attn_mfma_f32_kernel<TQ, D>), dim3((a.nitems + 3) / 4), dim3(256), lds, st, a);
+    return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
+}
+
 template <typename T, int TQ, int DP>
 static int launch_attn_mfma(const adk_op& op, hipStream_t st)
 {
@@ -394,7 +587,12 @@ static int launch_attn_16(const adk_op& op, hipStream_t st, bool d64)
 int launch_attn(const adk_op& op, hipStream_t st)
 {
     const bool d64 = op.i0 == 64;                           // head dim: op.i0 (0 = 32)
-    if (op.dtype == ADK_F32) return d64 ? launch_attn_valu<float, 64>(op, st) : launch_attn_valu<float, 32>(op, st);
+    if (op.dtype == ADK_F32) {
+        if (op.L >= 128 && op.P * 4 <= 64)                  // exact-fp32 matrix instruction from s = 128 up
+            return d64 ? launch_attn_mfma_f32<1, 64>(op, st)
+                       : (op.L >= 512 ? launch_attn_mfma_f32<2, 32>(op, st) : launch_attn_mfma_f32<1, 32>(op, st));
+        return d64 ? launch_attn_valu<float, 64>(op, st) : launch_attn_valu<float, 32>(op, st);
+    }
     if (op.dtype == ADK_F16) return launch_attn_16<f16_t>(op, st, d64);
     return launch_attn_16<bf16_t>(op, st, d64);
 }

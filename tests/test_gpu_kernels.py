@@ -309,12 +309,10 @@ def test_attention_vs_golden(env, golden_blocks, dt, s):
 def test_attention_core(env, dt, B, heads, s):
     """adk_attn1d alone (softmax(q k^T / sqrt(32)) v per head) vs an fp32 CPU reference on the same (rounded)
     inputs: ragged key tiles, sequences from 8 to 4096 (the long-context config), both query-tile widths of
-    the MFMA kernel.  Scores are spread (|q.k| up to ~8) so the online-softmax rescale branch is exercised,
+    the MFMA kernels (16-bit, and from s = 128 the exact-fp32 matrix-instruction kernel of the f32 path).  Scores are spread (|q.k| up to ~8) so the online-softmax rescale branch is exercised,
     and one key row per head is spiked to force a late running-max jump."""
     lib, _lib, layout, dev = env
     dtype, adk, _ = DT[dt]
-    if dt == "f32" and s > 1100:
-        pytest.skip("the exact-fp32 VALU kernel is only used at the short levels of the fp32 parity path")
     Cc, P, cb = heads * 32, 2, layout.chunk(dtype)
     g = torch.Generator().manual_seed(s * 7 + heads)
     qkv = torch.randn(B, 3 * Cc, s, generator=g) * 1.3

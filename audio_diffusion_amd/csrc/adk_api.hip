@@ -93,6 +93,13 @@ static int validate(const adk_op& o)
             REQUIRE(o.i1 >= 0 && o.i1 < 4095, "conv1d + GroupNorm fusion: slot %d outside [0, 4095)", o.i1);
             REQUIRE(!o.partials_out || o.residual, "conv1d + GroupNorm fusion: output statistics are built for the residual form");
         }
+        if (o.flags & ADK_FLAG_PRE_NORM) {
+            REQUIRE(o.taps == 1 && !(o.flags & (ADK_FLAG_FUSE_GN | ADK_FLAG_GROUP_STATS | ADK_FLAG_ELU | ADK_FLAG_CAUSAL)),
+                    "conv1d: the folded input GroupNorm is built for plain 1x1 convs");
+            REQUIRE(o.partials_in && o.n_partials_in >= 1 && o.gamma && o.bias, "conv1d + folded input GroupNorm: needs the "
+                    "input's partials, the weight row sums (gamma) and the folded bias");
+            REQUIRE(o.i2 >= 1 && o.i2 <= o.Cin && o.f0 > 0.f, "conv1d + folded input GroupNorm: channels i2=%d, eps=%g", o.i2, (double)o.f0);
+        }
         if (o.flags & ADK_FLAG_SKIP_CONV) {
             REQUIRE(o.flags & ADK_FLAG_FUSE_GN, "conv1d: the folded skip conv belongs to the conv + GroupNorm fusion");
             REQUIRE(o.L > 128, "conv1d: the folded skip conv is built for the pipelined kernel (L > 128)");

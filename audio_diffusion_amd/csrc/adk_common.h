@@ -140,6 +140,23 @@ __device__ __forceinline__ void gn_finalize(const float* __restrict__ partials, 
     rstd = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// The same by ONE wave on its own (no LDS, no barrier): lanes take every 64th pair, xor butterfly in double; every lane
+// gets the result.  Fixed order -> bit-reproducible.
+__device__ __forceinline__ void gn_finalize_wave(const float* __restrict__ partials, int n, double count, float eps,
+                                                 float& mean, float& rstd) {
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x & 63; i < n; i += 64) {
+        const float2 p = *reinterpret_cast<const float2*>(partials + 2 * i);
+        s += (double)p.x; q += (double)p.y;
+    }
+    s = wave_sum(s); q = wave_sum(q);
+    const double mu = s / count;
+    double var = q / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean = (float)mu;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
 // exact GELU (nn.GELU default, approximate='none'): 0.5*x*(1+erf(x/sqrt(2)))
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));

@@ -20,6 +20,10 @@ struct ConvArgs {
     unsigned gn_slot, gn_cap;             // gn_cap: resident block slots of the kernel on this device (0xffffffff: experiment, no tickets)
     int npb, gelu;               // tiles per sample (= tps * ncot)
     float eps; double gn_count;  // Cout * L
+    // ADK_FLAG_PRE_NORM: GroupNorm(1, Cin) of the INPUT folded into the conv (attention's norm -> qkv_proj): the weights carry
+    // gamma, `gamma` = row sums u of the packed weights, `beta` = bias + W beta_gn, and the epilogue applies
+    // y = rstd_b * acc + (beta[co] - mean_b * rstd_b * gamma[co]) with the sample's statistics from pn_partials [B][pn_n][2]
+    const float* pn_partials; int pn_n;
     const void* w2; int nchunks2;   // ADK_FLAG_SKIP_CONV: packed 1x1 weights of the folded skip conv, channel chunks of its input (= residual)
 };
 

@@ -100,6 +100,24 @@ __global__ __launch_bounds__(256, (TCO * TPOS >= 4 ? 1 : 2)) void conv_ksplit_ke
             }
     }
 
+    // ADK_FLAG_PRE_NORM (plain epilogue only): y = rstd_b * acc + (beta[co] - mean_b * rstd_b * gamma[co]).  pn_rs = 1 and
+    // bpre = bias otherwise: v * 1 + bias is the plain result, bit for bit.
+    float pn_rs = 1.f;
+    if constexpr (!GN) {
+        if (a.pn_partials) {
+            float mean, rstd;
+            gn_finalize_wave(a.pn_partials + (long long)b * a.pn_n * 2, a.pn_n, a.gn_count, a.eps, mean, rstd);
+            pn_rs = rstd;
+            const float mrs = mean * rstd;
+#pragma unroll
+            for (int i = 0; i < TCO; ++i) {
+                const int c = cobase + i * 32 + 8 * wave + 4 * (lane >> 5);
+                const float4 u = *reinterpret_cast<const float4*>(a.gamma + c), v = *reinterpret_cast<const float4*>(a.beta + c);
+                bpre[i] = make_float4(v.x - mrs * u.x, v.y - mrs * u.y, v.z - mrs * u.z, v.w - mrs * u.w);
+            }
+        }
+    }
+
     Frag fa[DEPTH][TAPS][TCO][2], fb[DEPTH][TAPS][TPOS][2];
     f32x16 acc[TCO][TPOS];
 #pragma unroll
@@ -275,7 +293,8 @@ __global__ __launch_bounds__(256, (TCO * TPOS >= 4 ? 1 : 2)) void conv_ksplit_ke
                 const float4 p = red[((sw * S + i * TPOS + j) * 4 + wave) * 64 + lane];
                 v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
             }
-            v[0] += bpre[i].x; v[1] += bpre[i].y; v[2] += bpre[i].z; v[3] += bpre[i].w;
+            v[0] = v[0] * pn_rs + bpre[i].x; v[1] = v[1] * pn_rs + bpre[i].y;
+            v[2] = v[2] * pn_rs + bpre[i].z; v[3] = v[3] * pn_rs + bpre[i].w;
             if (lvalid && co < a.Cout_alloc) {
                 const long long off = (((long long)(co / CBO) * a.M + m) * CBO) + (co % CBO);
                 if (rg) {

@@ -42,6 +42,12 @@ void conv_fill_args(const adk_op& op, int BN, int BM, ConvArgs& a)
         a.gelu = (op.flags & ADK_FLAG_GELU) ? 1 : 0;
         a.eps = op.f0; a.gn_count = (double)op.Cout * (double)op.L;
     }
+    a.pn_partials = nullptr; a.pn_n = 0;
+    if (op.flags & ADK_FLAG_PRE_NORM) {                      // bias travels as `beta`: it is applied AFTER the per-sample scale
+        a.pn_partials = op.partials_in; a.pn_n = op.n_partials_in;
+        a.gamma = op.gamma; a.beta = reinterpret_cast<const float*>(op.bias); a.bias = nullptr;
+        a.eps = op.f0; a.gn_count = (double)op.i2 * (double)op.L;
+    }
     a.w2 = nullptr; a.nchunks2 = 0;
     if (op.flags & ADK_FLAG_SKIP_CONV) { a.w2 = op.w2; a.nchunks2 = op.i2 / CB; }
 }
@@ -123,7 +129,7 @@ int launch_conv(const adk_op& op, hipStream_t st)
     const ConvTile ct = conv_tile(op);
     if (ct.ksplit) return launch_conv_ksplit(op, st);
     if (op.flags & ADK_FLAG_FUSE_GN) return launch_conv_gn(op, st);
-    if ((op.flags & (ADK_FLAG_CAUSAL | ADK_FLAG_ELU | ADK_FLAG_GROUP_STATS)) || op.i0 > 1) return launch_conv_ext(op, st);
+    if ((op.flags & (ADK_FLAG_CAUSAL | ADK_FLAG_ELU | ADK_FLAG_GROUP_STATS | ADK_FLAG_PRE_NORM)) || op.i0 > 1) return launch_conv_ext(op, st);
     if (op.dtype == ADK_F32) return launch_taps<float, float>(op, st);
     if (op.dtype == ADK_F16)
         return (op.flags & ADK_FLAG_OUT_F32) ? launch_taps<f16_t, float>(op, st) : launch_taps<f16_t, f16_t>(op, st);

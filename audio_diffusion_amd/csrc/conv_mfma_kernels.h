@@ -37,6 +37,28 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16 (&a
     // 25).  The bias is not loaded here at all: the accumulators START at the bias (conv_acc_init, fetched while the
     // first tiles are in flight), so acc already is conv + bias.
     ADK_TS(4)
+    // ADK_FLAG_PRE_NORM (EXT only): y = rstd_b * acc + (beta[co] - mean_b * rstd_b * gamma[co]); the shifts of this lane's
+    // channels are built before the first store
+    f32x2 pnA[TCO][4], pnB[TCO][4], pn_rs = {1.f, 1.f};
+    bool prenorm = false;
+    if constexpr (EXT) {
+        prenorm = a.pn_partials != nullptr;
+        if (prenorm) {
+            float mean, rstd;
+            gn_finalize_wave(a.pn_partials + (long long)b * a.pn_n * 2, a.pn_n, a.gn_count, a.eps, mean, rstd);
+            pn_rs.x = pn_rs.y = rstd;
+            const float mrs = mean * rstd;
+#pragma unroll
+            for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = cobase + (wco * TCO + i) * 32 + 8 * g + 4 * h;
+                    const float4 u = *reinterpret_cast<const float4*>(a.gamma + co), v = *reinterpret_cast<const float4*>(a.beta + co);
+                    pnA[i][g].x = v.x - mrs * u.x; pnA[i][g].y = v.y - mrs * u.y;
+                    pnB[i][g].x = v.z - mrs * u.z; pnB[i][g].y = v.w - mrs * u.w;
+                }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < TPOS; ++j) {
         const int l = l0 + (wpos * TPOS + j) * 32 + l31;
@@ -70,6 +92,9 @@ __device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16 (&a
                     va[gg].x = acc[i][j][4 * G]; va[gg].y = acc[i][j][4 * G + 1];
                     vb[gg].x = acc[i][j][4 * G + 2]; vb[gg].y = acc[i][j][4 * G + 3];
                     if (lvalid && co < a.Cout_alloc) {
+                        if constexpr (EXT) {
+                            if (prenorm) { va[gg] = va[gg] * pn_rs + pnA[i][G]; vb[gg] = vb[gg] * pn_rs + pnB[i][G]; }
+                        }
                         if constexpr (RES) {
                             float rr[4];
                             raw_to_float4(rraw[i][G], rr, TO());

@@ -89,6 +89,7 @@ class _Plan:
         # conv + GroupNorm fusion (ADK_FLAG_FUSE_GN, include/adk.h): state words {epoch, error, counters[4095]} and the
         # statistics-exchange workspace, both allocated first and never released (the arena starts zeroed)
         self.fuse_gn = bool(getattr(model, "fuse_gn", True))
+        self.fold_attn_norm = bool(getattr(model, "fold_attn_norm", True))   # attention's GroupNorm inside qkv_proj (ADK_FLAG_PRE_NORM)
         self.fold_skip = bool(getattr(model, "fold_skip", True))      # 1x1 skip convs inside the fused conv + GroupNorm launch
         self._gn_state = self._gn_ws = None
         self._gn_slots = 0
@@ -361,13 +362,49 @@ class _Plan:
             self.free(raw2)
         return y, pout
 
+    def conv_prenorm(self, x, px, key, norm, proj, Cout):
+        """proj(norm(x)) as ONE 1x1 conv on the raw x (ADK_FLAG_PRE_NORM): GroupNorm(1, C) is affine per sample, so
+        W (gamma (x - mu) r + beta) + b = r (W diag(gamma)) x + (b + W beta) - mu r rowsum(W diag(gamma)); the per-sample
+        scalars (mu, r) come from the producer's partials inside the conv's epilogue."""
+        bn = self.lib.adk_conv_cotile(self.adk_dtype, Cout, x.L)
+        cout_pad = _ceil_to(Cout, bn)
+        cin_alloc = _ceil_to(x.C, 16 if x.f32 else 32)
+        w = proj.weight.detach().float().cpu()
+        g, bt = norm.weight.detach().float().cpu(), norm.bias.detach().float().cpu()
+        wg = w * g[None, :, None]
+
+        def make_u():                       # row sums of the weights AS THE KERNEL SEES THEM (rounded to the compute dtype)
+            return wg.to(self.dtype).float().sum((1, 2))
+        vb = (proj.bias.detach().float().cpu() if proj.bias is not None else torch.zeros(Cout)) + (w[:, :, 0] @ bt)
+        y = self.tensor(Cout, x.L)
+        ptrs = {"x": ("arena", x.off), "y": ("arena", y.off), "partials_in": ("arena", px.off),
+                "w": ("abs", self._packed_conv(key + ".prenorm", wg, cin_alloc, cout_pad)),
+                "gamma": ("abs", self._dev(("pn_u", key, cout_pad), lambda: self._pad_to(make_u(), cout_pad))),
+                "bias": ("abs", self._padded_vec(key + ".prenorm.bias", vb, cout_pad))}
+        op = self._emit(_lib.OP_CONV, ptrs, flags=_lib.FLAG_PRE_NORM, L=x.L, Cin=cin_alloc, Cout=Cout, CoutPad=cout_pad,
+                        taps=1, n_partials_in=px.C, i2=x.C, f0=GN_EPS)
+        self.meta[-1].update(taps=1, L=x.L, cin=x.C, cout=Cout, cotile=self.lib.adk_conv_cotile_used(ctypes.byref(op)),
+                             postile=self.lib.adk_conv_postile(ctypes.byref(op)), flops=2.0 * x.C * Cout * x.L * self.B,
+                             bytes=float(self.B) * x.L * (cin_alloc + Cout) * (4 if x.f32 else 2)
+                             + float(cin_alloc) * cout_pad * (4 if x.f32 else 2), fused_gn=False, fused_skip=False)
+        return y
+
+    def _pad_to(self, v, n):
+        out = torch.zeros(n, device=self.device, dtype=torch.float32)
+        out[:v.numel()] = v.to(self.device)
+        return out
+
     def attention(self, att, key, x, px, out=None):
         """SelfAttention1d (reference blocks/blocks.py:113-122).  Frees x and px."""
-        n, _ = self.gn_apply(x, px, key + "norm", att.norm.weight, att.norm.bias, gelu=False,
-                             out=self.tensor(x.C, x.L))
-        self.free(px)
-        qkv, _ = self.conv(n, key + "qkv_proj", att.qkv_proj.weight, att.qkv_proj.bias, 3 * x.C)
-        self.free(n)
+        if self.fold_attn_norm:
+            qkv = self.conv_prenorm(x, px, key + "qkv_proj", att.norm, att.qkv_proj, 3 * x.C)
+            self.free(px)
+        else:
+            n, _ = self.gn_apply(x, px, key + "norm", att.norm.weight, att.norm.bias, gelu=False,
+                                 out=self.tensor(x.C, x.L))
+            self.free(px)
+            qkv, _ = self.conv(n, key + "qkv_proj", att.qkv_proj.weight, att.qkv_proj.bias, 3 * x.C)
+            self.free(n)
         y = self.tensor(x.C, x.L)
         self._emit(_lib.OP_ATTN, {"x": ("arena", qkv.off), "y": ("arena", y.off)}, L=x.L, Cin=x.C)
         self.meta[-1].update(L=x.L, c=x.C, attn_flops=4.0 * x.L * x.L * x.C * self.B)      # QK^T + PV

@@ -98,6 +98,12 @@ enum {
                                    y = [GELU](GroupNorm(conv(x))) + conv1x1(residual, w2), summed in the fp32 accumulators.
                                    Pipelined kernel only (L > 128). */
 
+#define ADK_FLAG_PRE_NORM 4096u  /* CONV, taps = 1: nn.GroupNorm(1, Cin) of the INPUT folded into the conv (SelfAttention1d's
+                                   norm -> qkv_proj, blocks/blocks.py:107,115): w = W diag(gamma_gn) (packed), bias = b + W beta_gn,
+                                   gamma = row sums of the packed w as f32 [CoutPad], partials_in / n_partials_in = (sum, sumsq)
+                                   partials of x, i2 = logical channel count of x, f0 = eps:
+                                   y = rstd_b * conv(x, w) + bias - mean_b * rstd_b * gamma.  Not with ADK_FLAG_FUSE_GN. */
+
 /* One flat descriptor for every op kind; unused fields are 0/NULL.  Field use per kind is
  * documented at the matching adk_* entry point below (same names). */
 typedef struct adk_op {

@@ -330,6 +330,53 @@ def test_attention_core(env, dt, B, heads, s):
     assert float(full[:, :, :P].abs().max()) == 0.0 and float(full[:, :, P + s:].abs().max()) == 0.0, "halo rows not zero"
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("B,L,Cin,Cout", [(2, 8, 64, 192), (3, 64, 512, 1536), (2, 100, 96, 288), (2, 256, 512, 1536),
+                                          (2, 1000, 64, 192), (1, 4096, 128, 384)])
+def test_conv_with_folded_input_groupnorm(env, dt, B, L, Cin, Cout):
+    """ADK_FLAG_PRE_NORM: conv1x1(GroupNorm(1, Cin)(x)) (SelfAttention1d's norm -> qkv_proj, blocks/blocks.py:107,115) as ONE
+    conv on the raw x with the norm folded into weights / epilogue, vs the fp32 composition of the ATen ops; the k-split
+    kernel (L <= 64) and the pipelined tiles (64, 128 and 256 positions).  x gets a mean of about one standard deviation."""
+    lib, _lib, layout, dev = env
+    dtype, adk, tol = DT[dt]
+    P, cb = 2, layout.chunk(dtype)
+    g = torch.Generator().manual_seed(L + Cin)
+    x = torch.randn(B, Cin, L, generator=g) * 1.5 + 1.2
+    w = torch.randn(Cout, Cin, 1, generator=g) / Cin ** 0.5
+    bias = torch.randn(Cout, generator=g) * 0.3
+    gamma, beta = torch.randn(Cin, generator=g) * 0.5 + 1.0, torch.randn(Cin, generator=g) * 0.2
+    xq = quant(x, dtype)
+    ref = F.conv1d(F.group_norm(xq, 1, gamma, beta, 1e-5), w, bias)
+    cin_alloc = (Cin + cb - 1) // cb * cb
+    bn = lib.adk_conv_cotile(adk, Cout, L)
+    cout_pad = (Cout + bn - 1) // bn * bn
+    wg = w * gamma[None, :, None]
+    wd = pack_w(wg, cin_alloc, cout_pad, cb, dtype, dev)
+    u, vb = torch.zeros(cout_pad), torch.zeros(cout_pad)
+    u[:Cout] = wg.to(dtype).float().sum((1, 2))
+    vb[:Cout] = bias + w[:, :, 0] @ beta
+    u, vb = u.to(dev), vb.to(dev)
+    xd = layout.to_cpl(x.to(dev), dtype, P)
+    sop = _lib.AdkOp()
+    sop.kind, sop.dtype, sop.L, sop.Cin = _lib.OP_GN_STATS, adk, L, Cin
+    n = lib.adk_partials_count(C.byref(sop))
+    part = torch.zeros(B, n, 2, device=dev)
+    assert lib.adk_gn_stats(adk, B, L, P, Cin, xd.data_ptr(), part.data_ptr(), sp()) == 0
+    planes = (Cout + cb - 1) // cb
+    yd = torch.full((planes, B, L + 2 * P, cb), 3.0, dtype=dtype, device=dev)
+    op = _lib.AdkOp()
+    op.kind, op.dtype, op.flags = _lib.OP_CONV, adk, _lib.FLAG_PRE_NORM
+    op.B, op.L, op.P, op.Cin, op.Cout, op.CoutPad, op.taps = B, L, P, cin_alloc, Cout, cout_pad, 1
+    op.i2, op.f0, op.n_partials_in = Cin, 1e-5, n
+    op.x, op.w, op.bias, op.gamma, op.partials_in, op.y = (xd.data_ptr(), wd.data_ptr(), vb.data_ptr(), u.data_ptr(),
+                                                          part.data_ptr(), yd.data_ptr())
+    assert lib.adk_run_plan(C.byref(op), 1, sp()) == 0, lib.adk_last_error()
+    torch.cuda.synchronize()
+    full = layout.from_cpl(yd, planes * cb).cpu()
+    assert rel_err(full[:, :Cout, P:P + L], ref) <= (2e-5 if dt == "f32" else tol)
+    assert float(full[:, :, :P].abs().max()) == 0.0 and float(full[:, :, P + L:].abs().max()) == 0.0, "halo rows not zero"
+
+
 FUSED_CASES = [
     # B, L, Cin, Cout, taps, residual, stats
     (3, 300, 64, 128, 5, False, False),     # 128x128 tiles, ragged, one round

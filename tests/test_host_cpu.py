@@ -68,7 +68,9 @@ def test_full_model_init_matches_reference_digest():
     # 203 GroupNorms: 167 of them ride in the epilogue of the conv that feeds them (ADK_FLAG_FUSE_GN: every k=5 conv of
     # a ResConvBlock but the last block's, which has no norm), the 36 attention norms stay passes of their own
     fused = sum(1 for i in range(plan.n_ops) if plan.ops[i].kind == _lib.OP_CONV and plan.ops[i].flags & _lib.FLAG_FUSE_GN)
-    assert fused == 167 and kinds.count(_lib.OP_GN_APPLY) == 203 - fused
+    # ... and the 36 attention norms are folded into the qkv_proj weights (ADK_FLAG_PRE_NORM): no GroupNorm pass is left
+    prenorm = sum(1 for i in range(plan.n_ops) if plan.ops[i].kind == _lib.OP_CONV and plan.ops[i].flags & _lib.FLAG_PRE_NORM)
+    assert fused == 167 and prenorm == 36 and kinds.count(_lib.OP_GN_APPLY) == 203 - fused - prenorm == 0
     # 168 k=5 + 72 qkv/out projections + 5 skips: the other 14 skip convs (every one above the k-split levels but the
     # last block's) run inside the fused launch of their block's second conv (ADK_FLAG_SKIP_CONV)
     folded = sum(1 for i in range(plan.n_ops) if plan.ops[i].kind == _lib.OP_CONV and plan.ops[i].flags & _lib.FLAG_SKIP_CONV)
@@ -80,7 +82,7 @@ def test_full_model_init_matches_reference_digest():
     m.fold_skip = True
     assert len({plan.ops[i].i1 for i in range(plan.n_ops) if plan.ops[i].flags & _lib.FLAG_FUSE_GN
                 and plan.ops[i].kind == _lib.OP_CONV}) == fused          # one ticket counter per fused conv
-    m.fuse_gn = False                                 # the unfused plan stays available (A/B, and > 512 tiles per sample)
+    m.fuse_gn = m.fold_attn_norm = False              # the unfused plan stays available (A/B, and > 512 tiles per sample)
     plain = _Plan(m, 1, 65536, torch.bfloat16, torch.device("cpu"))
     plain.validate()
     assert [plain.ops[i].kind for i in range(plain.n_ops)].count(_lib.OP_GN_APPLY) == 203

@@ -118,7 +118,9 @@ def cpu_baseline(model, calls, budget):
 
 
 def conv_roofline(model, B, dtype, dev, reps=3):
-    """HIP-event timing of every k=5 MFMA conv launch of one denoiser call, on the launch stream."""
+    """HIP-event timing of every k=5 MFMA conv launch of one denoiser call, on the launch stream.  Launches are grouped
+    by KERNEL SYMBOL (tile shape and epilogue variant: each group is one row of the rocprofv3 kernel statistics);
+    the dominant kernel is the group that carries the most FLOPs."""
     import torch
     from audio_diffusion_amd import _lib
     plan = model.plan_for(B, T, dtype, dev)
@@ -127,10 +129,19 @@ def conv_roofline(model, B, dtype, dev, reps=3):
     out = torch.empty_like(x)
     plan.bind(x.data_ptr(), tt.data_ptr(), out.data_ptr())
     stream = torch.cuda.current_stream(dev)
+    key = {v: k for k, v in dtypes().items()}[dtype]
     groups = {}
     for i, m in enumerate(plan.meta):
         if m["kind"] == _lib.OP_CONV and m["taps"] == 5 and m["cotile"] >= 128:
-            groups.setdefault(f'{m["cotile"]}co x {m["postile"]}pos', []).append(i)
+            op = plan.ops[i]
+            tpos = m["postile"] // 64
+            if m.get("fused_gn"):
+                res = int(bool(op.residual) and not m.get("fused_skip"))
+                name = (f"conv_mfma_gn_kernel<{key}, TAPS=5, TPOS={tpos}, RES={res}, STATS={int(bool(op.partials_out))}, "
+                        f"SKIP={int(bool(m.get('fused_skip')))}>")
+            else:
+                name = f"conv_mfma_kernel<{key}, TAPS=5, TPOS={tpos}>"
+            groups.setdefault(name, []).append(i)
     timed = set(i for g in groups.values() for i in g)
     ms = {i: 0.0 for i in timed}
     for r in range(reps + 1):
@@ -148,48 +159,63 @@ def conv_roofline(model, B, dtype, dev, reps=3):
         if r:                                        # first pass is a warm-up
             for i, (e0, e1) in evs.items():
                 ms[i] += e0.elapsed_time(e1) / reps
-    key = {v: k for k, v in dtypes().items()}[dtype]
     per = {}
-    for pt, idx in groups.items():
+    for name, idx in groups.items():
         fl = sum(plan.meta[i]["flops"] for i in idx)
         tm = sum(ms[i] for i in idx)
-        per[pt] = {"launches_per_call": len(idx), "avg_launch_us": 1e3 * tm / len(idx), "flop_per_call": fl,
-                   "tflops": fl / (tm * 1e-3) / 1e12, "ms_per_call": tm}
+        per[name] = {"launches_per_call": len(idx), "avg_launch_us": 1e3 * tm / len(idx), "flop_per_call": fl,
+                     "tflops": fl / (tm * 1e-3) / 1e12, "ms_per_call": tm}
     dom = max(per, key=lambda k: per[k]["flop_per_call"])
     d = per[dom]
     alg_bytes = sum(plan.meta[i]["bytes"] for i in groups[dom]) / len(groups[dom])
-    return {"bound": "mfma", "kernel": f"conv_mfma_kernel<{key}, taps=5, tile {dom}>",
+    allfl = sum(v["flop_per_call"] for v in per.values())
+    alltm = sum(v["ms_per_call"] for v in per.values())
+    return {"bound": "mfma", "kernel": dom,
+            "kernel_does": ("Conv1d k=5 + GroupNorm(1,C) + GELU (+ residual add | + the block's 1x1 skip conv) in ONE launch; "
+                            "FLOPs counted: the convolutions only" if "gn_kernel" in dom else "Conv1d k=5 (+ bias, GroupNorm partials)"),
             "achieved": d["tflops"], "peak": PEAK[key], "unit": "TFLOP/s", "frac": d["tflops"] / PEAK[key],
-            "traffic": pmc_traffic(key, dom), "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
+            "traffic": pmc_traffic(dom), "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
             "separate --pmc passes, profiles/)", "algorithmic_bytes_per_launch": alg_bytes,
             "launches_per_call": d["launches_per_call"], "avg_launch_us": d["avg_launch_us"],
             "flop_per_launch_avg": d["flop_per_call"] / d["launches_per_call"],
             "share_of_call_flop": d["flop_per_call"] / (FLOP_PER_CALL_PER_SAMPLE * B),
-            "other_tiles": {str(k): {"tflops": v["tflops"], "launches_per_call": v["launches_per_call"],
-                                     "avg_launch_us": v["avg_launch_us"]} for k, v in per.items() if k != dom}}
+            "all_k5_mfma_convs": {"tflops": allfl / (alltm * 1e-3) / 1e12, "ms_per_call": alltm,
+                                  "share_of_call_flop": allfl / (FLOP_PER_CALL_PER_SAMPLE * B)},
+            "other_kernels": {k: {"tflops": v["tflops"], "launches_per_call": v["launches_per_call"],
+                                  "avg_launch_us": v["avg_launch_us"]} for k, v in per.items() if k != dom}}
 
 
-def pmc_traffic(key, tile):
+def mangled(name):
+    """The symbol rocprofv3 prints for one of the names conv_roofline builds."""
+    import re
+    el = {"bf16": "DF16b", "f16": "DF16_", "fp32": "f"}
+    m = re.match(r"conv_mfma_gn_kernel<(\w+), TAPS=5, TPOS=(\d), RES=(\d), STATS=(\d), SKIP=(\d)>", name)
+    if m:
+        e = el[m.group(1)]
+        return f"_Z19conv_mfma_gn_kernelI{e}Li5ELi{m.group(2)}ELb{m.group(3)}ELb{m.group(4)}ELb{m.group(5)}EEv8ConvArgs"
+    m = re.match(r"conv_mfma_kernel<(\w+), TAPS=5, TPOS=(\d)>", name)
+    if m:
+        e = el[m.group(1)]
+        return f"_Z16conv_mfma_kernelILb0E{e}{e}Li5ELi2ELi2ELi2ELi{m.group(2)}ELi1EEv8ConvArgs"
+    return None
+
+
+def pmc_traffic(name):
     """HBM bytes per launch of the dominant kernel from the committed counter summary (tools/run_pmc.sh ->
     profiles/rNN/pmc_summary.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction).
     bench.py cannot collect counters itself; null when no summary covers this kernel and dtype."""
     import glob
-    import re
-    m = re.match(r"(\d+)co x (\d+)pos", tile)
-    if not m or key not in ("bf16", "f16"):
+    sym = mangled(name)
+    if sym is None:
         return None
-    tpos = int(m.group(2)) // 64
-    el = "DF16b" if key == "bf16" else "DF16_"
-    # conv_mfma_kernel<EXT=false, T, TO, TAPS=5, WCO=2, WPOS=2, TCO=2, TPOS, DIL=1> (older summaries: no EXT / DIL)
-    pat = re.compile(rf"_Z16conv_mfma_kernelI(Lb0E)?{el}{el}Li5ELi2ELi2ELi2ELi{tpos}E(Li1E)?Ev8ConvArgs$")
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary*.json")), reverse=True):
         try:
             summary = json.load(open(f))
         except (OSError, ValueError):
             continue
-        for name, e in summary.items():
-            if pat.match(name) and "hbm_bytes_per_launch" in e:
-                return e["hbm_bytes_per_launch"]
+        e = summary.get(sym)
+        if e and "hbm_bytes_per_launch" in e:
+            return e["hbm_bytes_per_launch"]
     return None
 
 

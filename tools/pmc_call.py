@@ -17,7 +17,7 @@ which = os.environ.get("PMC_CONFIG", "2")          # "2" (bench.py's workload: t
 if which in ("2", "both"):
     torch.manual_seed(0)
     m = A.DiffusionAttnUnet1D(n_attn_layers=4).to(dev).eval()
-    m.compute_dtype = torch.bfloat16
+    m.compute_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "fp32": torch.float32}[os.environ.get("PMC_DTYPE", "f16")]
     m.use_graph = False                      # eager launches: one profiler record per kernel
     x = torch.randn(16, 2, 65536, device=dev)
     A.sample(m, x, calls, 0)

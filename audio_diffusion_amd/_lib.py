@@ -36,6 +36,7 @@ OP_LINEAR, OP_FOURIER = 16, 17
 
 FLAG_GELU, FLAG_OUT_F32, FLAG_NOISE, FLAG_ADA, FLAG_LOG, FLAG_NO_EMBED, FLAG_GROUP_STATS, FLAG_WT = 1, 2, 4, 8, 16, 32, 64, 128
 FLAG_CAUSAL, FLAG_ELU, FLAG_FUSE_GN, FLAG_SKIP_CONV, FLAG_PRE_NORM = 256, 512, 1024, 2048, 4096
+FLAG_QKV = 8192
 
 
 class AdkOp(C.Structure):

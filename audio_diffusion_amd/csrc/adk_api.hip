@@ -147,6 +147,14 @@ static int validate(const adk_op& o)
         REQUIRE(o.Cin >= 32 && o.Cin % (o.i0 ? o.i0 : 32) == 0, "attn1d: C=%d must be a multiple of the head dim %d", o.Cin,
                 o.i0 ? o.i0 : 32);
         REQUIRE(o.x && o.y, "attn1d: null tensor");
+        if (o.flags & ADK_FLAG_QKV) {
+            REQUIRE(o.dtype != ADK_F32 && (o.i0 == 0 || o.i0 == 32) && o.L <= 256 && o.P * 4 <= 64,
+                    "attn1d + qkv projection: built for 16-bit dtypes, head dim 32, L <= 256 (got dtype %d, L=%d)", o.dtype, o.L);
+            REQUIRE(o.w && o.bias && o.gamma && o.partials_in && o.n_partials_in >= 1, "attn1d + qkv projection: needs the folded "
+                    "weights, bias, weight row sums (gamma) and the input's partials");
+            REQUIRE(o.CoutPad >= 3 * o.Cin && o.i2 >= 1 && o.i2 <= o.Cin && o.f0 > 0.f,
+                    "attn1d + qkv projection: CoutPad=%d < 3 C, or channels i2=%d / eps=%g out of range", o.CoutPad, o.i2, (double)o.f0);
+        }
         return ADK_OK;
     case ADK_OP_PACK_INPUT:
         if ((rc = check_geo(o, "pack_input"))) return rc;

@@ -549,6 +549,254 @@ static int launch_attn_mfma_f32(const adk_op& op, hipStream_t st)
     return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Short sequences (s <= 256, head dim 32, 16-bit): norm -> qkv_proj -> attention core in ONE launch (ADK_FLAG_QKV).
+// One block per (sample, head).  Phase 1: the head's 96 rows of the folded projection (ADK_FLAG_PRE_NORM form: the
+// weights carry the GroupNorm's gamma, the per-sample (mean, rstd) scale the result) times the raw x[C, s], operands
+// straight from global memory in fragment layout (wave w owns position tiles w and w + 4, chunks double-buffered in
+// registers); q, k, v land in LDS as [position][32] rows.  Phase 2: attn_mfma_kernel's flash loop with every operand
+// read from LDS (V^T by ds_read_b64_tr_b16 straight from the v rows).  Saves a launch and the qkv tensor per
+// attention block at the levels where a launch costs more than its work (36 per call of the uncond model).
+struct AttnQkvArgs {
+    const void* x; const void* w; const float* u; const float* vb; const float* partials; void* y;
+    int B, L, P, Lp; long long M;
+    int C, heads, CoutPad, pn_n;
+    float eps; double count;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_qkv_kernel(const AttnQkvArgs a)
+{
+    typedef typename AttMma<T>::Frag Frag;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hd = blockIdx.x % a.heads, b = blockIdx.x / a.heads;
+    const long long srow = (long long)b * a.Lp + a.P;
+    const int last = a.L - 1;
+    const int npt = (a.L + 31) >> 5;                        // 32-row tiles (<= 8)
+    unsigned char* lq = smem;                               // [which][npt * 32][64 B]
+    const int region = npt * 2048;
+
+    float mean, rstd;
+    gn_finalize_wave(a.partials + (long long)b * a.pn_n * 2, a.pn_n, a.count, a.eps, mean, rstd);
+    const float mrs = mean * rstd;
+
+    // ---- phase 1: q, k, v of this head ----
+    // s > 64: wave w owns position tiles w and w + 4 and walks all channel chunks.  s <= 64 (at most two tiles): the chunk
+    // chain is what costs time, so every wave takes all tiles and every fourth chunk; the four partial accumulators meet
+    // in LDS and are added in wave order (fixed -> bit-reproducible).
+    {
+        const bool ksplit = npt <= 2;                       // block-uniform
+        const unsigned char* xg = reinterpret_cast<const unsigned char*>(a.x) + srow * 64 + h * 16;
+        const unsigned char* wg = reinterpret_cast<const unsigned char*>(a.w) + (long long)(hd * 32 + l31) * 64 + h * 16;
+        const long long xplane = a.M * 64, wchunk = (long long)a.CoutPad * 64, wwhich = (long long)a.C * 64;
+        const int nck = a.C >> 5;
+        const int c0 = ksplit ? wave : 0, cs = ksplit ? 4 : 1;
+        const int nmy = nck > c0 ? (nck - c0 + cs - 1) / cs : 0;
+        int pos[2], ptile[2];
+        bool act[2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            ptile[jt] = ksplit ? jt : wave + 4 * jt;
+            act[jt] = ptile[jt] < npt;                      // wave-uniform
+            const int p = ptile[jt] * 32 + l31;
+            pos[jt] = p > last ? last : p;
+        }
+        f32x16 acc[3][2];
+#pragma unroll
+        for (int wh = 0; wh < 3; ++wh)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[wh][jt][r] = 0.f;
+        if (act[0] && nmy > 0) {
+            Frag fa[2][3][2], fb[2][2][2];
+#define ADK_AQ_LOAD(D_, I_)                                                                                  \
+            {                                                                                                \
+                const int kc_ = c0 + (I_) * cs;                                                              \
+                const unsigned char* wp_ = wg + (long long)kc_ * wchunk;                                     \
+                const unsigned char* xp_ = xg + (long long)kc_ * xplane;                                     \
+                _Pragma("unroll") for (int wh = 0; wh < 3; ++wh)                                             \
+                    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                         \
+                        fa[D_][wh][ks] = *reinterpret_cast<const Frag*>(wp_ + wh * wwhich + ks * 32);        \
+                _Pragma("unroll") for (int jt = 0; jt < 2; ++jt)                                             \
+                    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                         \
+                        fb[D_][jt][ks] = *reinterpret_cast<const Frag*>(xp_ + (long long)pos[jt] * 64 + ks * 32); \
+            }
+            ADK_AQ_LOAD(0, 0)
+            if (nmy > 1) ADK_AQ_LOAD(1, 1)
+            for (int i0 = 0; i0 < nmy; i0 += 2) {
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    if (i0 + d < nmy) {
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                            for (int wh = 0; wh < 3; ++wh) {
+                                acc[wh][0] = AttMma<T>::run(fa[d][wh][ks], fb[d][0][ks], acc[wh][0]);
+                                if (act[1]) acc[wh][1] = AttMma<T>::run(fa[d][wh][ks], fb[d][1][ks], acc[wh][1]);
+                            }
+                        if (i0 + d + 2 < nmy) ADK_AQ_LOAD(d, i0 + d + 2)
+                    }
+                }
+            }
+#undef ADK_AQ_LOAD
+        }
+        float4* red = reinterpret_cast<float4*>(smem + 3 * region);      // [wave][which][tile][g][lane], k-split only
+        if (ksplit) {
+#pragma unroll
+            for (int wh = 0; wh < 3; ++wh)
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt)
+                    if (act[jt]) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            red[(((wave * 3 + wh) * 2 + jt) * 4 + g) * 64 + lane] =
+                                make_float4(acc[wh][jt][4 * g], acc[wh][jt][4 * g + 1], acc[wh][jt][4 * g + 2], acc[wh][jt][4 * g + 3]);
+                    }
+            __syncthreads();
+        }
+        // scale / shift, round, park as [position][32] rows: lane (pos = l31, h) holds channels (r & 3) + 8 (r >> 2) + 4 h.
+        // k-split: wave w finishes the (which, tile) pairs w and w + 4 of the six.
+#pragma unroll
+        for (int wh = 0; wh < 3; ++wh)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const bool mine = ksplit ? (act[jt] && ((wh * 2 + jt) & 3) == wave) : act[jt];
+                if (mine) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float4 v = make_float4(acc[wh][jt][4 * g], acc[wh][jt][4 * g + 1], acc[wh][jt][4 * g + 2], acc[wh][jt][4 * g + 3]);
+                        if (ksplit) {
+                            v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                            for (int sw = 0; sw < 4; ++sw) {
+                                const float4 p4 = red[(((sw * 3 + wh) * 2 + jt) * 4 + g) * 64 + lane];
+                                v.x += p4.x; v.y += p4.y; v.z += p4.z; v.w += p4.w;
+                            }
+                        }
+                        const int co = wh * a.C + hd * 32 + 8 * g + 4 * h;
+                        const float4 u4 = *reinterpret_cast<const float4*>(a.u + co), v4 = *reinterpret_cast<const float4*>(a.vb + co);
+                        const int row = ptile[jt] * 32 + l31;
+                        const uint2 pk = make_uint2(
+                            pack2(v.x * rstd + (v4.x - mrs * u4.x), v.y * rstd + (v4.y - mrs * u4.y), T()),
+                            pack2(v.z * rstd + (v4.z - mrs * u4.z), v.w * rstd + (v4.w - mrs * u4.w), T()));
+                        *reinterpret_cast<uint2*>(lq + wh * region + row * 64 + (8 * g + 4 * h) * 2) = pk;
+                    }
+                }
+            }
+    }
+    __syncthreads();
+
+    // ---- phase 2: flash loop of attn_mfma_kernel (TQ = 1), operands from LDS ----
+    const unsigned char* lk = lq + region;
+    const unsigned char* lv = lq + 2 * region;
+    const int voff = (4 * h + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    const float c = 0.25503486f;                            // log2(e) * 32^-1/2
+    unsigned char* yb = reinterpret_cast<unsigned char*>(a.y) + ((long long)hd * a.M + srow) * 64;
+    for (int qt = wave; qt < npt; qt += 4) {
+        Frag qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[ks] = *reinterpret_cast<const Frag*>(lq + (qt * 32 + l31) * 64 + (2 * ks + h) * 16);
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+        float mrun = -INFINITY, lrun = 0.f;
+        for (int kt = 0; kt < npt; ++kt) {
+            Frag kf[2], vf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                kf[ks] = *reinterpret_cast<const Frag*>(lk + (kt * 32 + l31) * 64 + (2 * ks + h) * 16);
+#pragma unroll
+            for (int sgrp = 0; sgrp < 2; ++sgrp) {
+                union { s16x4 v[2]; Frag f; } cv;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    cv.v[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(lv + kt * 2048 + voff + (16 * sgrp + 8 * u) * 64));
+                vf[sgrp] = cv.f;
+            }
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+            st = AttMma<T>::run(kf[0], qf[0], st);
+            st = AttMma<T>::run(kf[1], qf[1], st);
+            if ((kt + 1) * 32 > a.L) {                      // wave-uniform: only the last tile can be partial
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h > last) st[r] = -INFINITY;
+            }
+            float mx = st[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(mrun, mx * c);
+            const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+            mrun = mnew;
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                st[r] = __builtin_amdgcn_exp2f(st[r] * c - mnew);
+                ps += st[r];
+            }
+            lrun = lrun * alpha + ps;
+            Frag pf[2];
+#pragma unroll
+            for (int sgrp = 0; sgrp < 2; ++sgrp) {
+                union { uint32_t w[4]; Frag f; } pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f32x2 pv;
+                    pv.x = st[8 * sgrp + 2 * e]; pv.y = st[8 * sgrp + 2 * e + 1];
+                    pk.w[e] = pack2v(pv, T());
+                }
+                pf[sgrp] = pk.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] *= alpha;
+            o = AttMma<T>::run(vf[0], pf[0], o);
+            o = AttMma<T>::run(vf[1], pf[1], o);
+        }
+        const float ltot = lrun + __shfl_xor(lrun, 32, 64);
+        const float inv = 1.0f / ltot;
+        const int q = qt * 32 + l31;
+        if (q <= last) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<uint2*>(yb + (long long)q * 64 + (8 * g + 4 * h) * 2) =
+                    make_uint2(pack2(o[4 * g] * inv, o[4 * g + 1] * inv, T()), pack2(o[4 * g + 2] * inv, o[4 * g + 3] * inv, T()));
+        }
+    }
+    if (wave == 0 && lane < a.P * 4) {                      // halo rows of this head's plane
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        const int row = lane >> 2, pc = lane & 3;
+        *reinterpret_cast<uint4*>(yb + (long long)(row - a.P) * 64 + pc * 16) = z;
+        *reinterpret_cast<uint4*>(yb + (long long)(a.L + row) * 64 + pc * 16) = z;
+    }
+}
+
+template <typename T>
+static int launch_attn_qkv(const adk_op& op, hipStream_t st)
+{
+    AttnQkvArgs a;
+    a.x = op.x; a.w = op.w; a.u = op.gamma; a.vb = reinterpret_cast<const float*>(op.bias); a.partials = op.partials_in; a.y = op.y;
+    a.B = op.B; a.L = op.L; a.P = op.P; a.Lp = op.L + 2 * op.P; a.M = (long long)op.B * a.Lp;
+    a.C = op.Cin; a.heads = op.Cin / 32; a.CoutPad = op.CoutPad; a.pn_n = op.n_partials_in;
+    a.eps = op.f0; a.count = (double)op.i2 * (double)op.L;
+    const int npt = (op.L + 31) / 32;
+    const size_t lds = (size_t)3 * npt * 2048 + (npt <= 2 ? (size_t)4 * 3 * 2 * 4 * 64 * 16 : 0);   // + the k-split partials
+    static bool attr_set = false;             // > 64 KiB of dynamic LDS needs the opt-in, once per kernel
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_qkv_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                3 * 2 * 2048 + 4 * 3 * 2 * 4 * 64 * 16) != hipSuccess) return ADK_ELAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attn_qkv_kernel<T>), dim3(op.B * a.heads), dim3(256), lds, st, a);
+    return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
+}
+
 template <typename T, int TQ, int DP>
 static int launch_attn_mfma(const adk_op& op, hipStream_t st)
 {
@@ -586,6 +834,7 @@ static int launch_attn_16(const adk_op& op, hipStream_t st, bool d64)
 
 int launch_attn(const adk_op& op, hipStream_t st)
 {
+    if (op.flags & ADK_FLAG_QKV) return op.dtype == ADK_F16 ? launch_attn_qkv<f16_t>(op, st) : launch_attn_qkv<bf16_t>(op, st);
     const bool d64 = op.i0 == 64;                           // head dim: op.i0 (0 = 32)
     if (op.dtype == ADK_F32) {
         if (op.L >= 128 && op.P * 4 <= 64)                  // exact-fp32 matrix instruction from s = 128 up

@@ -90,6 +90,7 @@ class _Plan:
         # statistics-exchange workspace, both allocated first and never released (the arena starts zeroed)
         self.fuse_gn = bool(getattr(model, "fuse_gn", True))
         self.fold_attn_norm = bool(getattr(model, "fold_attn_norm", True))   # attention's GroupNorm inside qkv_proj (ADK_FLAG_PRE_NORM)
+        self.fuse_qkv_attn = bool(getattr(model, "fuse_qkv_attn", True))     # L <= 256: qkv_proj inside the attention launch (ADK_FLAG_QKV)
         self.fold_skip = bool(getattr(model, "fold_skip", True))      # 1x1 skip convs inside the fused conv + GroupNorm launch
         self._gn_state = self._gn_ws = None
         self._gn_slots = 0
@@ -362,10 +363,10 @@ class _Plan:
             self.free(raw2)
         return y, pout
 
-    def conv_prenorm(self, x, px, key, norm, proj, Cout):
-        """proj(norm(x)) as ONE 1x1 conv on the raw x (ADK_FLAG_PRE_NORM): GroupNorm(1, C) is affine per sample, so
-        W (gamma (x - mu) r + beta) + b = r (W diag(gamma)) x + (b + W beta) - mu r rowsum(W diag(gamma)); the per-sample
-        scalars (mu, r) come from the producer's partials inside the conv's epilogue."""
+    def _prenorm_params(self, x, key, norm, proj, Cout):
+        """Folded form of proj(norm(x)) for ADK_FLAG_PRE_NORM / ADK_FLAG_QKV: GroupNorm(1, C) is affine per sample, so
+        W (gamma (x - mu) r + beta) + b = r (W diag(gamma)) x + (b + W beta) - mu r rowsum(W diag(gamma)).  Returns the
+        pointer dict {w, gamma (= row sums), bias} and (cin_alloc, cout_pad)."""
         bn = self.lib.adk_conv_cotile(self.adk_dtype, Cout, x.L)
         cout_pad = _ceil_to(Cout, bn)
         cin_alloc = _ceil_to(x.C, 16 if x.f32 else 32)
@@ -376,11 +377,17 @@ class _Plan:
         def make_u():                       # row sums of the weights AS THE KERNEL SEES THEM (rounded to the compute dtype)
             return wg.to(self.dtype).float().sum((1, 2))
         vb = (proj.bias.detach().float().cpu() if proj.bias is not None else torch.zeros(Cout)) + (w[:, :, 0] @ bt)
-        y = self.tensor(Cout, x.L)
-        ptrs = {"x": ("arena", x.off), "y": ("arena", y.off), "partials_in": ("arena", px.off),
-                "w": ("abs", self._packed_conv(key + ".prenorm", wg, cin_alloc, cout_pad)),
+        ptrs = {"w": ("abs", self._packed_conv(key + ".prenorm", wg, cin_alloc, cout_pad)),
                 "gamma": ("abs", self._dev(("pn_u", key, cout_pad), lambda: self._pad_to(make_u(), cout_pad))),
                 "bias": ("abs", self._padded_vec(key + ".prenorm.bias", vb, cout_pad))}
+        return ptrs, cin_alloc, cout_pad
+
+    def conv_prenorm(self, x, px, key, norm, proj, Cout):
+        """proj(norm(x)) as ONE 1x1 conv on the raw x (ADK_FLAG_PRE_NORM); the per-sample scalars (mu, r) come from the
+        producer's partials inside the conv's epilogue."""
+        ptrs, cin_alloc, cout_pad = self._prenorm_params(x, key, norm, proj, Cout)
+        y = self.tensor(Cout, x.L)
+        ptrs.update({"x": ("arena", x.off), "y": ("arena", y.off), "partials_in": ("arena", px.off)})
         op = self._emit(_lib.OP_CONV, ptrs, flags=_lib.FLAG_PRE_NORM, L=x.L, Cin=cin_alloc, Cout=Cout, CoutPad=cout_pad,
                         taps=1, n_partials_in=px.C, i2=x.C, f0=GN_EPS)
         self.meta[-1].update(taps=1, L=x.L, cin=x.C, cout=Cout, cotile=self.lib.adk_conv_cotile_used(ctypes.byref(op)),
@@ -396,6 +403,20 @@ class _Plan:
 
     def attention(self, att, key, x, px, out=None):
         """SelfAttention1d (reference blocks/blocks.py:113-122).  Frees x and px."""
+        if (self.fold_attn_norm and self.fuse_qkv_attn and self.dtype != torch.float32 and x.L <= 256 and self.P <= 16
+                and x.C % 32 == 0 and att.n_head * 32 == x.C):
+            # short levels: norm -> qkv_proj -> attention core as ONE launch (ADK_FLAG_QKV), no qkv tensor
+            ptrs, cin_alloc, cout_pad = self._prenorm_params(x, key + "qkv_proj", att.norm, att.qkv_proj, 3 * x.C)
+            y = self.tensor(x.C, x.L)
+            ptrs.update({"x": ("arena", x.off), "y": ("arena", y.off), "partials_in": ("arena", px.off)})
+            self._emit(_lib.OP_ATTN, ptrs, flags=_lib.FLAG_QKV, L=x.L, Cin=x.C, CoutPad=cout_pad, n_partials_in=px.C,
+                       i2=x.C, f0=GN_EPS)
+            self.meta[-1].update(L=x.L, c=x.C, attn_flops=4.0 * x.L * x.L * x.C * self.B, fused_qkv=True,
+                                 flops=2.0 * x.C * 3 * x.C * x.L * self.B)
+            self.free(px)
+            o, _ = self.conv(y, key + "out_proj", att.out_proj.weight, att.out_proj.bias, x.C, residual=x, out=out)
+            self.free(y, x)
+            return o
         if self.fold_attn_norm:
             qkv = self.conv_prenorm(x, px, key + "qkv_proj", att.norm, att.qkv_proj, 3 * x.C)
             self.free(px)

@@ -104,6 +104,11 @@ enum {
                                    partials of x, i2 = logical channel count of x, f0 = eps:
                                    y = rstd_b * conv(x, w) + bias - mean_b * rstd_b * gamma.  Not with ADK_FLAG_FUSE_GN. */
 
+#define ADK_FLAG_QKV 8192u       /* ATTN, 16-bit dtypes, head dim 32, L <= 256: norm -> qkv_proj -> attention core in one launch
+                                   (blocks/blocks.py:113-121 without the out_proj): x is the block's INPUT, CPL [B, Cin, L];
+                                   w / bias / gamma / partials_in / n_partials_in / i2 / f0 exactly as ADK_FLAG_PRE_NORM describes
+                                   them for the qkv projection (CoutPad = rows of the packed w >= 3 Cin); y CPL [B, Cin, L]. */
+
 /* One flat descriptor for every op kind; unused fields are 0/NULL.  Field use per kind is
  * documented at the matching adk_* entry point below (same names). */
 typedef struct adk_op {

@@ -304,6 +304,59 @@ def test_attention_vs_golden(env, golden_blocks, dt, s):
     assert rel_err(y, ref) <= (1e-5 if dt == "f32" else 2e-2)
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("s", [8, 64, 256])
+def test_attention_block_fused_qkv_vs_golden(env, golden_blocks, dt, s):
+    """ADK_FLAG_QKV: SelfAttention1d's norm -> qkv_proj -> attention core as ONE launch (+ the out_proj conv with the
+    residual) vs the reference module's golden output; and bit-reproducible across two launches."""
+    lib, _lib, layout, dev = env
+    dtype, adk, tol = DT[dt]
+    z = golden_blocks
+    sd = sub_sd(z, f"attn{s}/sd/")
+    x = torch.from_numpy(z[f"attn{s}/x"])
+    ref = torch.from_numpy(z[f"attn{s}/y"])
+    B, Cc, L = x.shape
+    P, cb = 2, layout.chunk(dtype)
+    xd = layout.to_cpl(x.to(dev), dtype, P)
+    sop = _lib.AdkOp()
+    sop.kind, sop.dtype, sop.L, sop.Cin = _lib.OP_GN_STATS, adk, L, Cc
+    n = lib.adk_partials_count(C.byref(sop))
+    part = torch.zeros(B, n, 2, device=dev)
+    assert lib.adk_gn_stats(adk, B, L, P, Cc, xd.data_ptr(), part.data_ptr(), sp()) == 0
+    w, bq = sd["qkv_proj.weight"].float(), sd["qkv_proj.bias"].float()
+    g, bt = sd["norm.weight"].float(), sd["norm.bias"].float()
+    cout_pad = (3 * Cc + 127) // 128 * 128
+    wg = w * g[None, :, None]
+    wd = pack_w(wg, Cc, cout_pad, cb, dtype, dev)
+    u, vb = torch.zeros(cout_pad), torch.zeros(cout_pad)
+    u[:3 * Cc] = wg.to(dtype).float().sum((1, 2))
+    vb[:3 * Cc] = bq + w[:, :, 0] @ bt
+    u, vb = u.to(dev), vb.to(dev)
+    op = _lib.AdkOp()
+    op.kind, op.dtype, op.flags = _lib.OP_ATTN, adk, _lib.FLAG_QKV
+    op.B, op.L, op.P, op.Cin, op.CoutPad, op.i2, op.f0, op.n_partials_in = B, L, P, Cc, cout_pad, Cc, 1e-5, n
+    op.x, op.w, op.bias, op.gamma, op.partials_in = xd.data_ptr(), wd.data_ptr(), vb.data_ptr(), u.data_ptr(), part.data_ptr()
+    outs = []
+    for _ in range(2):
+        yd = torch.full_like(xd, 3.0)
+        op.y = yd.data_ptr()
+        assert lib.adk_run_plan(C.byref(op), 1, sp()) == 0, lib.adk_last_error()
+        torch.cuda.synchronize()
+        outs.append(yd)
+    assert torch.equal(outs[0].view(torch.uint8), outs[1].view(torch.uint8))
+    yd = outs[0]
+    assert float(yd[:, :, :P].abs().max()) == 0.0 and float(yd[:, :, P + L:].abs().max()) == 0.0, "halo rows not zero"
+    wo = pack_w(sd["out_proj.weight"], Cc, 128, cb, dtype, dev)
+    bo = torch.zeros(128, device=dev)
+    bo[:Cc] = sd["out_proj.bias"].to(dev)
+    od = torch.empty_like(xd)
+    assert lib.adk_conv1d(adk, 0, B, L, P, Cc, Cc, 128, 1, yd.data_ptr(), wo.data_ptr(), bo.data_ptr(), xd.data_ptr(),
+                          od.data_ptr(), None, sp()) == 0, lib.adk_last_error()
+    torch.cuda.synchronize()
+    y = layout.from_cpl(od, Cc).cpu()[:, :, P:P + L]
+    assert rel_err(y, ref) <= 2e-2
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("B,heads,s", [(2, 2, 8), (3, 1, 100), (1, 3, 257), (2, 2, 1024), (1, 2, 4096), (1, 1, 1000)])
 def test_attention_core(env, dt, B, heads, s):

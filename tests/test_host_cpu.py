@@ -69,16 +69,24 @@ def test_full_model_init_matches_reference_digest():
     # a ResConvBlock but the last block's, which has no norm), the 36 attention norms stay passes of their own
     fused = sum(1 for i in range(plan.n_ops) if plan.ops[i].kind == _lib.OP_CONV and plan.ops[i].flags & _lib.FLAG_FUSE_GN)
     # ... and the 36 attention norms are folded into the qkv_proj weights (ADK_FLAG_PRE_NORM): no GroupNorm pass is left
-    prenorm = sum(1 for i in range(plan.n_ops) if plan.ops[i].kind == _lib.OP_CONV and plan.ops[i].flags & _lib.FLAG_PRE_NORM)
+    # (all six attention levels of this model have L <= 256: the folded projection runs inside the attention launch itself,
+    # ADK_FLAG_QKV; longer sequences keep qkv_proj as a conv of its own with ADK_FLAG_PRE_NORM)
+    prenorm = sum(1 for i in range(plan.n_ops) if plan.ops[i].kind == _lib.OP_ATTN and plan.ops[i].flags & _lib.FLAG_QKV)
     assert fused == 167 and prenorm == 36 and kinds.count(_lib.OP_GN_APPLY) == 203 - fused - prenorm == 0
-    # 168 k=5 + 72 qkv/out projections + 5 skips: the other 14 skip convs (every one above the k-split levels but the
+    long_plan = _Plan(A.DiffusionAttnUnet1D(depth=4, c_mults=[32, 32, 64, 64], n_attn_layers=2), 1, 8192, torch.float16,
+                      torch.device("cpu"))
+    long_plan.validate()
+    lk = [(long_plan.ops[i].kind, long_plan.ops[i].flags, long_plan.ops[i].L) for i in range(long_plan.n_ops)]
+    assert any(k == _lib.OP_CONV and f & _lib.FLAG_PRE_NORM and L > 256 for k, f, L in lk)
+    assert not any(k == _lib.OP_ATTN and f & _lib.FLAG_QKV and L > 256 for k, f, L in lk)
+    # 168 k=5 + 36 out projections (the 36 qkv projections run inside the attention launches) + 5 skips: the other 14 skip convs (every one above the k-split levels but the
     # last block's) run inside the fused launch of their block's second conv (ADK_FLAG_SKIP_CONV)
     folded = sum(1 for i in range(plan.n_ops) if plan.ops[i].kind == _lib.OP_CONV and plan.ops[i].flags & _lib.FLAG_SKIP_CONV)
-    assert folded == 14 and kinds.count(_lib.OP_CONV) == 259 - folded
+    assert folded == 14 and kinds.count(_lib.OP_CONV) == 259 - folded - 36
     m.fold_skip = False
     nofold = _Plan(m, 1, 65536, torch.bfloat16, torch.device("cpu"))
     nofold.validate()
-    assert [nofold.ops[i].kind for i in range(nofold.n_ops)].count(_lib.OP_CONV) == 259
+    assert [nofold.ops[i].kind for i in range(nofold.n_ops)].count(_lib.OP_CONV) == 259 - 36
     m.fold_skip = True
     assert len({plan.ops[i].i1 for i in range(plan.n_ops) if plan.ops[i].flags & _lib.FLAG_FUSE_GN
                 and plan.ops[i].kind == _lib.OP_CONV}) == fused          # one ticket counter per fused conv

@@ -19,6 +19,7 @@
 //   so neither P nor the [s,s] scores ever touch LDS, and the rescale factor is a per-lane scalar.
 // f32: attn_mfma_f32_kernel (s >= 128: the same structure on the exact-fp32 matrix instruction) and attn_kernel (short
 // sequences: one query row per lane, K/V tiles in LDS as fp32, exact fp32 VALU math); both hold rtol 1e-4.
+#include <stdlib.h>
 #include "adk_common.h"
 
 struct AttnArgs {
@@ -797,6 +798,224 @@ static int launch_attn_qkv(const adk_op& op, hipStream_t st)
     return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Long sequences (s >= 512, head dim 32, 16-bit): attn_mfma_lds_kernel.  Same arithmetic as attn_mfma_kernel, but the four
+// waves of a block own four consecutive query tiles of ONE (sample, head) and share every K/V tile: a 64-key stage
+// (4 KiB of K rows + 4 KiB of V rows) reaches LDS once per block by LDS-DMA (one global_load_lds_dwordx4 per wave for K
+// and one for V), three stages in a ring, one block barrier per stage.  attn_mfma_kernel has every wave stream the whole
+// K/V of its head from L2 on its own: four times the L2 traffic and a dependent global round trip per 32 keys.
+// K rows are XOR-swizzled through the DMA's source address (piece p of row r in slot p ^ ((r >> 2) & 3), as in the conv
+// kernels) so the ds_read_b128 fragment reads are conflict-free; V rows stay linear for ds_read_b64_tr_b16.
+template <int N> __device__ __forceinline__ void att_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void att_glds16(const unsigned char* src, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// ds_read_b64_tr_b16 as inline asm: the compiler treats the intrinsic as a read that may alias the LDS-DMA writes in flight
+// and puts a vmcnt(0) in front of it (draining the prefetched stages); the asm form is invisible to that bookkeeping, so
+// the lgkmcnt wait is written by hand (att_lds_wait, which carries the registers as in/out operands: a data dependency
+// the scheduler cannot move the consuming MFMAs across).
+__device__ __forceinline__ s16x4 att_ds_read_tr(const unsigned char* p) {
+    s16x4 r;
+    const unsigned addr = (unsigned)(size_t)((const __attribute__((address_space(3))) unsigned char*)p);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+    return r;
+}
+__device__ __forceinline__ void att_lds_wait(s16x4& a, s16x4& b, s16x4& c, s16x4& d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
+}
+
+template <typename T, int TQ>
+__global__ __launch_bounds__(256, 2) void attn_mfma_lds_kernel(const AttnMfmaArgs a)
+{
+    typedef typename AttMma<T>::Frag Frag;
+    constexpr int STAGE = 8192;                             // 64 keys: K rows then V rows
+    constexpr int UG = TQ < 2 ? TQ : 2;                     // query sub-tiles whose MFMAs / softmax are interleaved
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];    // [3][STAGE]
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nqb = (a.ntq + 3) >> 2;                       // blocks per (sample, head)
+    const int qb = blockIdx.x % nqb, rest = blockIdx.x / nqb, hd = rest % a.heads, b = rest / a.heads;
+    const int qt = qb * 4 + wave;                           // this wave's query tile (TQ * 32 queries)
+    const bool active = qt < a.ntq;                         // wave-uniform; idle waves still stage tiles and meet the barriers
+    const long long srow = (long long)b * a.Lp + a.P;
+    const int last = a.L - 1;
+    const long long pstride = a.M * 64;
+    const unsigned char* qg = reinterpret_cast<const unsigned char*>(a.qkv) + ((long long)hd * a.M + srow) * 64;
+    const unsigned char* kg = qg + (long long)a.heads * pstride;
+    const unsigned char* vg = kg + (long long)a.heads * pstride;
+
+    Frag qf[TQ][2];
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) {
+        int q = (qt * TQ + u) * 32 + l31;
+        q = q > last ? last : q;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[u][ks] = *reinterpret_cast<const Frag*>(qg + (long long)q * 64 + (2 * ks + h) * 16);
+    }
+
+    // staging: wave w moves rows 16 w .. 16 w + 15 of a stage's K tile and of its V tile (lane: slot lane & 3 of row lane >> 2)
+    const int srow16 = wave * 16 + (lane >> 2), sslot = lane & 3;
+    const int kswz = (sslot ^ ((srow16 >> 2) & 3)) << 4;    // source piece of this lane's K slot
+    auto stage_in = [&](int st) {
+        int key = st * 64 + srow16;
+        key = key > last ? last : key;                      // keys past the sample are masked below
+        unsigned char* dst = smem + (st % 3) * STAGE + wave * 1024;
+        att_glds16(kg + (long long)key * 64 + kswz, dst);
+        att_glds16(vg + (long long)key * 64 + (sslot << 4), dst + 4096);
+    };
+
+    f32x16 o[TQ];
+    float mrun[TQ], lrun[TQ];
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) {
+        mrun[u] = -INFINITY; lrun[u] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[u][r] = 0.f;
+    }
+    const int voff = (4 * h + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    const int kfo0 = l31 * 64 + (((0 + h) ^ ((l31 >> 2) & 3)) << 4), kfo1 = l31 * 64 + (((2 + h) ^ ((l31 >> 2) & 3)) << 4);
+    const float c = 0.25503486f;                            // log2(e) * 32^-1/2
+
+    const int nst = (a.L + 63) >> 6;
+    // The Q rows must have landed before the first LDS-DMA goes out, and the compiler has to KNOW it (intrinsic, not asm):
+    // otherwise its own bookkeeping puts a vmcnt(0) - which also drains the stages in flight - in front of every MFMA
+    // that reads qf.  One global round trip per block of 256 queries.
+    __builtin_amdgcn_s_waitcnt(0 | (0x7 << 4) | (0xf << 8));
+    asm volatile("" ::: "memory");
+    stage_in(0);
+    if (nst > 1) stage_in(1);
+    for (int st = 0; st < nst; ++st) {
+        if (st + 1 < nst) att_wait_vmcnt<2>(); else att_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (st + 2 < nst) stage_in(st + 2);                 // into the buffer stage st - 1 used: every wave is past it
+        if (!active) continue;
+        const unsigned char* kb = smem + (st % 3) * STAGE;
+        const unsigned char* vbase = kb + 4096;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int kt = st * 2 + half;                   // 32-key tile
+            if (kt * 32 > last) break;                      // wave-uniform
+            Frag kf[2], vf[2];
+            kf[0] = *reinterpret_cast<const Frag*>(kb + half * 2048 + kfo0);
+            kf[1] = *reinterpret_cast<const Frag*>(kb + half * 2048 + kfo1);
+            {
+                union { s16x4 v[2]; Frag f; } cv0, cv1;
+                cv0.v[0] = att_ds_read_tr(vbase + half * 2048 + voff);
+                cv0.v[1] = att_ds_read_tr(vbase + half * 2048 + voff + 8 * 64);
+                cv1.v[0] = att_ds_read_tr(vbase + half * 2048 + voff + 16 * 64);
+                cv1.v[1] = att_ds_read_tr(vbase + half * 2048 + voff + 24 * 64);
+                att_lds_wait(cv0.v[0], cv0.v[1], cv1.v[0], cv1.v[1]);
+                vf[0] = cv0.f; vf[1] = cv1.f;
+            }
+            const bool ragged = (kt + 1) * 32 > a.L;
+            // all score MFMAs of the tile first, then the softmax of every query sub-tile, then the P V MFMAs: the
+            // matrix-pipe latency of one sub-tile hides behind the VALU work of the other
+#pragma unroll
+            for (int u0 = 0; u0 < TQ; u0 += UG) {
+            f32x16 sc[TQ];
+#pragma unroll
+            for (int u = u0; u < u0 + UG; ++u) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[u][r] = 0.f;
+                sc[u] = AttMma<T>::run(kf[0], qf[u][0], sc[u]);
+                sc[u] = AttMma<T>::run(kf[1], qf[u][1], sc[u]);
+            }
+            Frag pf[TQ][2];
+            float alpha[TQ];
+            bool rescale[TQ];
+#pragma unroll
+            for (int u = u0; u < u0 + UG; ++u) {
+                if (ragged) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h > last) sc[u][r] = -INFINITY;
+                }
+                float mx = sc[u][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[u][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float mnew = fmaxf(mrun[u], mx * c);
+                alpha[u] = __builtin_amdgcn_exp2f(mrun[u] - mnew);
+                rescale[u] = __ballot(mnew != mrun[u]) != 0ull;
+                mrun[u] = mnew;
+                f32x2 ps2 = {0.f, 0.f};
+                const f32x2 c2 = {c, c}, m2 = {-mnew, -mnew};
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2 t2;
+                    t2.x = sc[u][r]; t2.y = sc[u][r + 1];
+                    t2 = t2 * c2 + m2;
+                    t2.x = __builtin_amdgcn_exp2f(t2.x); t2.y = __builtin_amdgcn_exp2f(t2.y);
+                    sc[u][r] = t2.x; sc[u][r + 1] = t2.y;
+                    ps2 += t2;
+                }
+                lrun[u] = lrun[u] * alpha[u] + (ps2.x + ps2.y);
+#pragma unroll
+                for (int sgrp = 0; sgrp < 2; ++sgrp) {
+                    union { uint32_t w[4]; Frag f; } pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        f32x2 pv;
+                        pv.x = sc[u][8 * sgrp + 2 * e]; pv.y = sc[u][8 * sgrp + 2 * e + 1];
+                        pk.w[e] = pack2v(pv, T());
+                    }
+                    pf[u][sgrp] = pk.f;
+                }
+            }
+#pragma unroll
+            for (int u = u0; u < u0 + UG; ++u) {
+                if (rescale[u]) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[u][r] *= alpha[u];
+                }
+                o[u] = AttMma<T>::run(vf[0], pf[u][0], o[u]);
+                o[u] = AttMma<T>::run(vf[1], pf[u][1], o[u]);
+            }
+            }
+        }
+    }
+    if (!active) return;
+
+    unsigned char* yb = reinterpret_cast<unsigned char*>(a.y) + ((long long)hd * a.M + srow) * 64;
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) {
+        const float ltot = lrun[u] + __shfl_xor(lrun[u], 32, 64);
+        const float inv = 1.0f / ltot;
+        const int q = (qt * TQ + u) * 32 + l31;
+        if (q <= last) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<uint2*>(yb + (long long)q * 64 + (8 * g + 4 * h) * 2) =
+                    make_uint2(pack2(o[u][4 * g] * inv, o[u][4 * g + 1] * inv, T()),
+                               pack2(o[u][4 * g + 2] * inv, o[u][4 * g + 3] * inv, T()));
+        }
+    }
+    if (qt == 0 || qt == a.ntq - 1) {                       // halo rows of this head's plane
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        if (lane < a.P * 4) {
+            const int row = lane >> 2, pc = lane & 3;
+            if (qt == 0) *reinterpret_cast<uint4*>(yb + (long long)(row - a.P) * 64 + pc * 16) = z;
+            if (qt == a.ntq - 1) *reinterpret_cast<uint4*>(yb + (long long)(a.L + row) * 64 + pc * 16) = z;
+        }
+    }
+}
+
+template <typename T, int TQ>
+static int launch_attn_mfma_lds(const adk_op& op, hipStream_t st)
+{
+    AttnMfmaArgs a;
+    a.qkv = op.x; a.y = op.y;
+    a.B = op.B; a.L = op.L; a.P = op.P; a.Lp = op.L + 2 * op.P; a.M = (long long)op.B * a.Lp;
+    a.heads = op.Cin / 32; a.ntq = (op.L + 32 * TQ - 1) / (32 * TQ);
+    a.nitems = op.B * a.heads * ((a.ntq + 3) / 4);          // blocks
+    hipLaunchKernelGGL((attn_mfma_lds_kernel<T, TQ>), dim3(a.nitems), dim3(256), 3 * 8192, st, a);
+    return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
+}
+
 template <typename T, int TQ, int DP>
 static int launch_attn_mfma(const adk_op& op, hipStream_t st)
 {
@@ -827,7 +1046,13 @@ static int launch_attn_16(const adk_op& op, hipStream_t st, bool d64)
 {
     if (op.P * 4 <= 64) {
         if (d64) return op.L >= 512 ? launch_attn_mfma<T, 2, 2>(op, st) : launch_attn_mfma<T, 1, 2>(op, st);
-        return op.L >= 512 ? launch_attn_mfma<T, 2, 1>(op, st) : launch_attn_mfma<T, 1, 1>(op, st);
+        if (op.L >= 512) {
+            static const bool own = getenv("ADK_ATTN_NO_LDS") != nullptr;      // experiment: every wave streams K/V itself
+            // (128 queries per wave, TQ = 4, was measured too: 280.9 vs 282.2 us at s = 4096, B = 4 and 924 vs 921 us at B = 16 -
+            // the loop is bound by the softmax's VALU work, not by operand delivery; not dispatched)
+            return own ? launch_attn_mfma<T, 2, 1>(op, st) : launch_attn_mfma_lds<T, 2>(op, st);
+        }
+        return launch_attn_mfma<T, 1, 1>(op, st);
     }
     return d64 ? launch_attn_valu<T, 64>(op, st) : launch_attn_valu<T, 32>(op, st);
 }

@@ -43,7 +43,8 @@ __device__ __forceinline__ void gn_gather(const ConvArgs& a, int b, unsigned epo
         }
         if (__all(ok)) break;
         if (++spins >= GN_SPIN_LIMIT) {               // bounded: a block that is not resident must not hang the GPU
-            if (lane == 0) __hip_atomic_store((gu32*)(a.gn_err), 0x600du + 1u, ADK_RLX_AGENT);
+            // 0x6sssbbbb... : which op (slot) and which sample ran out of patience
+            if (lane == 0) __hip_atomic_store((gu32*)(a.gn_err), 0x60000000u | (a.gn_slot << 12) | ((unsigned)b & 0xfffu), ADK_RLX_AGENT);
             break;
         }
         __builtin_amdgcn_s_sleep(8);

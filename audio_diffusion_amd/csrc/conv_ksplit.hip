@@ -44,13 +44,13 @@ __global__ __launch_bounds__(256, (TCO * TPOS >= 4 ? 1 : 2)) void conv_ksplit_ke
             unsigned* tick = reinterpret_cast<unsigned*>(smem);
             if (threadIdx.x == 0) {
                 const unsigned old = __hip_atomic_fetch_add((gu32*)(a.gn_ticket), 1u, ADK_RLX_AGENT);
-                *tick = old - (ebase - 1u) * a.nblk;
+                *tick = old - (ebase - 1u) * a.gn_grid;
             }
             __syncthreads();
             lid = __builtin_amdgcn_readfirstlane(*tick);
             __syncthreads();
-            if (lid >= a.nblk) {
-                if (threadIdx.x == 0) __hip_atomic_store((gu32*)(a.gn_err), 0x71c1u, ADK_RLX_AGENT);
+            if (lid >= a.nblk) {                             // a spare block (gn_spare), or - beyond the grid - counter out of step
+                if (lid >= a.gn_grid && threadIdx.x == 0) __hip_atomic_store((gu32*)(a.gn_err), 0x71c1u, ADK_RLX_AGENT);
                 return;
             }
             b = (int)(lid / (unsigned)a.npb);
@@ -375,7 +375,9 @@ static int launch_ks(const adk_op& op, hipStream_t st)
             }
             if (a.npb > cap[dev]) return ADK_EINVAL;
             a.gn_cap = (unsigned)cap[dev];
-            hipLaunchKernelGGL((conv_ksplit_kernel<T, TO, TAPS, TCO, TPOS, DEPTH, true>), dim3(a.nblk), dim3(256), lds, st, a);
+            // ticketed (more blocks than resident slots): spare blocks, see gn_spare; else every block is resident
+            hipLaunchKernelGGL((conv_ksplit_kernel<T, TO, TAPS, TCO, TPOS, DEPTH, true>),
+                               dim3(a.nblk > a.gn_cap ? a.gn_grid : a.nblk), dim3(256), lds, st, a);
             return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
         }
     }

@@ -113,7 +113,14 @@ class _FusedSampler:
             sp = torch.cuda.current_stream(x.device).cuda_stream
             for _ in range(self.steps):
                 self._one_step(sp)
-        return self.pred.clone()
+        out = self.pred.clone()
+        # the fused conv + GroupNorm launches wait, bounded, for the other tiles of a sample; a wait that ran out (or
+        # tickets out of step) leaves an error word instead of a hang: never hand back audio computed past one
+        err = self.plan.gn_error()
+        if err:
+            raise RuntimeError(f"libadk: a fused conv + GroupNorm launch flagged error {err:#x} during sample() "
+                               "(a tile waited in vain for its sample's statistics); the output was discarded")
+        return out
 
 
 @torch.no_grad()

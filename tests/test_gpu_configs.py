@@ -181,3 +181,21 @@ def test_config5_full_model_shard_of_32():
     pred = A.sample(m, x, 3, 0)                           # a short captured loop on the full shard
     assert torch.isfinite(pred).all()
     assert torch.equal(A.sample(m, x[17:18].contiguous(), 3, 0)[0], pred[17])
+
+
+def test_config5_two_gpu_shard_of_128_soak():
+    """configs[4] at N = 2: 128 samples per GPU.  Thousands of ticketed fused conv + GroupNorm launches over grids of up
+    to 36 864 blocks: with exactly one block per tile the LAST sample's tiles could be left in the queue of a lagging XCD
+    behind blocks waiting for them (a bounded wait expired about once per 10^4 launches at this batch); the launches
+    now carry spare blocks (gn_spare).  sample() raises if any launch flags its error word."""
+    import audio_diffusion_amd as A
+    torch.manual_seed(0)
+    m = A.DiffusionAttnUnet1D(n_attn_layers=4).eval().to(DEV)
+    m.compute_dtype = torch.float16
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(128, 2, 65536, generator=g).to(DEV)
+    pred = A.sample(m, x, 25, 0)
+    assert torch.isfinite(pred).all()
+    plan = [p for p in m._plans.values() if hasattr(p, "plan")][0].plan
+    assert plan.gn_error() == 0
+    assert torch.equal(A.sample(m, x[77:78].contiguous(), 25, 0)[0], pred[77]), "a sample's result must not depend on its shard"

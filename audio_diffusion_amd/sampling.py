@@ -54,6 +54,10 @@ def step_coefficients(steps, eta, warp=None):
     return tab
 
 
+class FusedLaunchError(RuntimeError):
+    """A fused conv + GroupNorm launch gave up waiting for a sample's statistics (error word of the plan's state)."""
+
+
 class _FusedSampler:
     """Captured step loop for one (model, B, T, dtype, steps)."""
 
@@ -118,8 +122,8 @@ class _FusedSampler:
         # tickets out of step) leaves an error word instead of a hang: never hand back audio computed past one
         err = self.plan.gn_error()
         if err:
-            raise RuntimeError(f"libadk: a fused conv + GroupNorm launch flagged error {err:#x} during sample() "
-                               "(a tile waited in vain for its sample's statistics); the output was discarded")
+            raise FusedLaunchError(f"libadk: a fused conv + GroupNorm launch flagged error {err:#x} during sample() "
+                                   "(a tile waited in vain for its sample's statistics); the output was discarded")
         return out
 
 
@@ -180,11 +184,23 @@ def _sample(model, x, steps, eta, warp, extra_args):
         dtype = model.resolve_dtype(in_sampler=True)
         cshape = tuple(cond.shape) if cond is not None else None
         key = ("sampler", x.shape[0], x.shape[2], dtype, str(x.device), steps, cshape)
-        smp = model._plans.get(key)
-        if smp is None:
-            smp = _FusedSampler(model, x, steps, dtype, use_graph=getattr(model, "use_graph", True), cond_shape=cshape)
-            model._plans[key] = smp
-        return smp.run(x, coef, cond)
+        for attempt in (0, 1):
+            smp = model._plans.get(key)
+            if smp is None:
+                smp = _FusedSampler(model, x, steps, dtype, use_graph=getattr(model, "use_graph", True), cond_shape=cshape)
+                model._plans[key] = smp
+            try:
+                return smp.run(x, coef, cond)
+            except FusedLaunchError as e:
+                # The in-launch exchange of GroupNorm statistics assumes this process has the GPU's block slots to itself
+                # (DESIGN.md section 4).  When it does not (another process on the same GPU), fall back ONCE to the plan with
+                # GroupNorm as passes of its own - slower, no in-kernel waiting - and say so.
+                if attempt or not getattr(model, "fuse_gn", True):
+                    raise
+                import warnings
+                warnings.warn(f"{e}; re-running with model.fuse_gn = False (GroupNorm as separate passes)")
+                model.fuse_gn = False
+                model._plans = {}
 
     # generic path: any callable model (or eta > 0); the update still runs as one fused kernel
     lib = _lib.load()

@@ -103,6 +103,7 @@ static int validate(const adk_op& o)
         if (o.flags & ADK_FLAG_SKIP_CONV) {
             REQUIRE(o.flags & ADK_FLAG_FUSE_GN, "conv1d: the folded skip conv belongs to the conv + GroupNorm fusion");
             REQUIRE(o.L > 128, "conv1d: the folded skip conv is built for the pipelined kernel (L > 128)");
+            REQUIRE(o.taps == 3 || o.taps == 5, "conv1d: the folded skip conv is built for 3 and 5 taps");
             REQUIRE(o.residual && o.w2, "conv1d + folded skip conv: needs the block input (residual) and the skip weights (w2)");
             REQUIRE(o.i2 >= cb && o.i2 % cb == 0, "conv1d + folded skip conv: input channels i2=%d not a multiple of %d", o.i2, cb);
         }

@@ -339,7 +339,8 @@ class _Plan:
             return y, None
         g2 = blk.main[4]
         if self.gn_fusable(h1, c2.weight, blk.c_out):        # conv -> GroupNorm -> GELU -> + skip(x) as one launch
-            fold = has_skip and self.fold_skip and h1.L > 128 and x.f32 == h1.f32     # pipelined kernel: skip conv inside too
+            fold = (has_skip and self.fold_skip and h1.L > 128 and x.f32 == h1.f32       # pipelined kernel: skip conv inside too
+                    and c2.weight.shape[2] in (3, 5))
             r = x
             if has_skip and not fold:
                 r, _ = self.conv(x, key + "skip", blk.skip.weight, None, blk.c_out)

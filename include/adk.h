@@ -96,7 +96,7 @@ enum {
                                    folded into the launch: `residual` is then the BLOCK INPUT, CPL [B, i2, L] (i2 = its channel
                                    count, a multiple of CB), w2 = the skip's packed weights [i2/CB][1][CoutPad][CB] (no bias), and
                                    y = [GELU](GroupNorm(conv(x))) + conv1x1(residual, w2), summed in the fp32 accumulators.
-                                   Pipelined kernel only (L > 128). */
+                                   Pipelined kernel only (L > 128), 3 or 5 taps. */
 
 #define ADK_FLAG_PRE_NORM 4096u  /* CONV, taps = 1: nn.GroupNorm(1, Cin) of the INPUT folded into the conv (SelfAttention1d's
                                    norm -> qkv_proj, blocks/blocks.py:107,115): w = W diag(gamma_gn) (packed), bias = b + W beta_gn,

@@ -450,7 +450,6 @@ FUSED_CASES = [
     (2, 200, 32, 96, 5, 32, True),          # 128x64 tile, pad channels, output statistics
     (2, 65536, 32, 128, 5, 64, False),      # 128x256 tiles, 256 per sample
     (5, 4100, 64, 256, 3, 128, True),       # two co tiles, 3 taps, more skip chunks than main chunks
-    (2, 1000, 96, 160, 7, 64, False),       # 7 taps
     (20, 4096, 128, 128, 5, 256, False),    # the up path's 2c -> c block: 8 skip chunks
 ]
 

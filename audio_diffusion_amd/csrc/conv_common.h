@@ -17,7 +17,7 @@ struct ConvArgs {
     const unsigned* gn_epoch;    // [0] = per-forward epoch base (advanced by an earlier kernel); the tag also carries gn_slot
     unsigned* gn_err;            // set to a non-zero code when a bounded wait runs out
     unsigned* gn_ticket;         // this op's tile counter (grows by nblk per forward)
-    unsigned gn_slot, gn_cap;             // gn_cap: resident block slots of the kernel on this device (0xffffffff: experiment, no tickets)
+    unsigned gn_slot, gn_cap;             // gn_cap: resident block slots of the kernel on this device
     unsigned gn_grid;                     // blocks launched when tiles go by ticket: nblk + gn_spare(nblk)
     int npb, gelu;               // tiles per sample (= tps * ncot)
     float eps; double gn_count;  // Cout * L

@@ -226,6 +226,12 @@ def _sample(model, x, steps, eta, warp, extra_args):
     finally:
         if auto:
             model.compute_dtype = prev
+    if isinstance(model, DiffusionAttnUnet1D):       # same rule as the captured loop: no audio past a flagged fused launch
+        for p in list(model._plans.values()):
+            err = getattr(p, "plan", p).gn_error()
+            if err:
+                raise FusedLaunchError(f"libadk: a fused conv + GroupNorm launch flagged error {err:#x} during sample(); set "
+                                       "model.fuse_gn = False (GroupNorm as separate passes) if this GPU is shared")
     return pred
 
 

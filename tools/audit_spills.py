@@ -2,10 +2,11 @@
 """Register-spill audit of the MFMA kernels (CPU only: hipcc cross-compiles to assembly).
 
 The pipelined convolution / attention loops wait for their LDS-DMA stages with COUNTED `s_waitcnt vmcnt(N)`.  A register
-the compiler keeps in scratch is reloaded with a VMEM instruction; inside such a loop that reload would be counted in
-vmcnt and a stage could be read before it has landed.  This tool compiles every kernel unit to assembly and fails if any
-kernel that uses LDS-DMA has a scratch access between its first and last MFMA (spills in prologues / epilogues are
-reported, not fatal).   usage: python tools/audit_spills.py [unit ...]"""
+the compiler keeps in scratch is reloaded with a VMEM instruction; inside such a loop the reload joins the in-order
+queue those waits look at.  That cannot make a wait too weak (vmcnt(N) still guarantees everything older than the N most
+recent entries), but it makes it stricter - the prefetched stages drain - and it adds a memory round trip to the loop.
+This tool compiles every kernel unit to assembly and fails if any kernel that uses LDS-DMA has a scratch access between
+its first and last MFMA (spills in prologues / epilogues are reported, not fatal).   usage: python tools/audit_spills.py [unit ...]"""
 import os, re, subprocess, sys, tempfile
 from concurrent.futures import ThreadPoolExecutor
 

@@ -26,29 +26,36 @@ __device__ __forceinline__ void gn_gather(const ConvArgs& a, int b, unsigned epo
 {
     gu64* gs = (gu64*)(a.gn_ws) + (size_t)b * a.npb * 2;
     const int ng = 2 * a.npb;
-    double acc_d = 0.0;
+    // Only the granules that have not arrived yet are read again: a sample's tiles finish over ~10 us, every one of up to
+    // 511 waiting blocks polls, and re-reading the whole list (up to 8 KiB, agent scope: it bypasses the L2s) on every
+    // poll would put a second output tensor's worth of traffic on the fabric while the late tiles still need it.
+    unsigned long long x[16];
+    unsigned have = 0;                                // bit k: x[k] holds this launch's value
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (lane + 64 * k >= ng) { x[k] = (unsigned long long)epoch << 32; have |= 1u << k; }      // value +0.0
     for (unsigned spins = 0;;) {
-        unsigned long long x[16];
+        unsigned long long v[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int idx = lane + 64 * k;
-            x[k] = idx < ng ? __hip_atomic_load(gs + idx, ADK_RLX_AGENT) : ((unsigned long long)epoch << 32);
-        }
-        bool ok = true;
-        acc_d = 0.0;
+        for (int k = 0; k < 16; ++k)                   // all the loads of this poll go out before the first tag is looked at
+            v[k] = (have & (1u << k)) ? x[k] : __hip_atomic_load(gs + lane + 64 * k, ADK_RLX_AGENT);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            ok &= (unsigned)(x[k] >> 32) == epoch;
-            acc_d += (double)__uint_as_float((unsigned)x[k]);
-        }
-        if (__all(ok)) break;
+        for (int k = 0; k < 16; ++k)
+            if ((unsigned)(v[k] >> 32) == epoch) { x[k] = v[k]; have |= 1u << k; }
+        if (__all(have == 0xffffu)) break;
         if (++spins >= GN_SPIN_LIMIT) {               // bounded: a block that is not resident must not hang the GPU
-            // 0x6sssbbbb... : which op (slot) and which sample ran out of patience
+            // 0x6sssbbb: which op (slot) and which sample ran out of patience
             if (lane == 0) __hip_atomic_store((gu32*)(a.gn_err), 0x60000000u | (a.gn_slot << 12) | ((unsigned)b & 0xfffu), ADK_RLX_AGENT);
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (!(have & (1u << k))) x[k] = 0;
             break;
         }
         __builtin_amdgcn_s_sleep(8);
     }
+    double acc_d = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc_d += (double)__uint_as_float((unsigned)x[k]);
 #pragma unroll
     for (int o = 32; o >= 2; o >>= 1) acc_d += __shfl_xor(acc_d, o, 64);        // within each parity class
     const double q = __shfl(acc_d, 1, 64), tot = __shfl(acc_d, 0, 64);

@@ -401,7 +401,8 @@ def main():
             "config": {"workload": (f"configs[1]: DiffusionAttnUnet1D uncond (221M params, random init seed 0), batch {total} x 2ch x {T}"
                                     if world == 1 else
                                     f"configs[4]: the same model, global batch {total} x 2ch x {T} sharded over {world} GPUs "
-                                    f"({per_gpu} per GPU), RCCL all-gather of the output audio inside the timed region")
+                                    f"({per_gpu} per GPU), {'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} all-gather "
+                                    "of the output audio inside the timed region")
                        + f", {a.ddim_steps}-step v-DDIM eta=0, hipGraph-captured step loop",
                        "batch_per_gpu": per_gpu, "global_batch": total, "ddim_steps": a.ddim_steps,
                        "parallelism": f"batch-parallel x{world}" + (" + all-gather of output" if world > 1 else "")},

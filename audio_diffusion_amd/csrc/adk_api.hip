@@ -90,7 +90,7 @@ static int validate(const adk_op& o)
             REQUIRE(o.gamma && o.beta && o.aux0 && o.aux1, "conv1d + GroupNorm fusion: needs gamma, beta, the epoch words (aux0) "
                     "and the granule workspace (aux1)");
             REQUIRE(o.f0 > 0.f, "conv1d + GroupNorm fusion: eps=%g", (double)o.f0);
-            REQUIRE(o.i1 >= 0 && o.i1 < 4095, "conv1d + GroupNorm fusion: slot %d outside [0, 4095)", o.i1);
+            REQUIRE(o.i1 >= 0 && o.i1 < 511, "conv1d + GroupNorm fusion: slot %d outside [0, 511)", o.i1);
             REQUIRE(!o.partials_out || o.residual, "conv1d + GroupNorm fusion: output statistics are built for the residual form");
         }
         if (o.flags & ADK_FLAG_PRE_NORM) {

@@ -10,6 +10,8 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 #define ADK_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 constexpr unsigned GN_SPIN_LIMIT = 1u << 20;     // ~1 us per poll: gives up after about a second
+constexpr unsigned GN_LIST_STRIDE = 512;         // words between the ticket counters of two XCDs' lists (separate L2 lines):
+                                                 // counter of (slot, XCD k) = counters[k * 512 + slot], slot < 511
 constexpr int GN_MAX_NPB = 512;                  // tiles per sample: 2 * 512 granules = 16 per lane of the sweeping wave
 
 // One lane publishes this tile's (sum, sumsq).

@@ -38,7 +38,7 @@ void conv_fill_args(const adk_op& op, int BN, int BM, ConvArgs& a)
         a.gn_epoch = reinterpret_cast<const unsigned*>(op.aux0);
         a.gn_err = const_cast<unsigned*>(reinterpret_cast<const unsigned*>(op.aux0)) + 1;
         a.gn_slot = (unsigned)op.i1;
-        a.gn_ticket = a.gn_err + 1 + op.i1;                  // aux0 = {epoch base, error, ticket counters[4095]}
+        a.gn_ticket = a.gn_err + 1 + op.i1;                  // aux0 = {epoch base, error, ticket counters[8 lists][512]}
         a.gelu = (op.flags & ADK_FLAG_GELU) ? 1 : 0;
         a.eps = op.f0; a.gn_count = (double)op.Cout * (double)op.L;
     }
@@ -71,6 +71,9 @@ int conv_gn_check(const adk_op& op, const char** why)
     }
     const int npb = ((op.L + t.bm - 1) / t.bm) * (op.CoutPad / t.bn);
     if (npb > 512) { *why = "more than 512 tiles per sample (they must all be in flight together)"; return 0; }
+    if (!t.ksplit && ((op.L + t.bm - 1) / t.bm + 7) / 8 * (op.CoutPad / t.bn) > 64) {
+        *why = "a sample's share of one XCD's ticket list exceeds the XCD's 64 block slots"; return 0;
+    }
     return 1;
 }
 

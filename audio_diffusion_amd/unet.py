@@ -86,7 +86,7 @@ class _Plan:
         self.meta = []            # per-op bookkeeping for profiling (algorithmic FLOPs / bytes)
         self._keep = []           # device tensors that must outlive the plan (weights, tables)
         self.t_table = t_table
-        # conv + GroupNorm fusion (ADK_FLAG_FUSE_GN, include/adk.h): state words {epoch, error, counters[4095]} and the
+        # conv + GroupNorm fusion (ADK_FLAG_FUSE_GN, include/adk.h): state words {epoch, error, counters[8][512]} and the
         # statistics-exchange workspace, both allocated first and never released (the arena starts zeroed)
         self.fuse_gn = bool(getattr(model, "fuse_gn", True))
         self.fold_attn_norm = bool(getattr(model, "fold_attn_norm", True))   # attention's GroupNorm inside qkv_proj (ADK_FLAG_PRE_NORM)
@@ -172,12 +172,12 @@ class _Plan:
         """Called before anything else is planned: the two regions must never share bytes with a buffer of the forward
         (a region taken later could land in a hole a released activation left, and that activation's producer would
         then overwrite the counters on every call)."""
-        self._gn_state = self.raw(16 * 1024 + 16)
+        self._gn_state = self.raw(8 + 8 * 512 * 4 + 64)      # {epoch, error, counters[8 XCD lists][512 slots]}
         self._gn_ws = self.raw(self.B * 512 * 16)
 
     def gn_fusable(self, x, w, Cout, out_f32=False):
         """Can conv(x, w) -> GroupNorm(1, Cout) run as ONE launch (adk_conv_gn_fusable)?"""
-        if not self.fuse_gn or out_f32 or self._gn_slots >= 4094 or self._gn_state is None:
+        if not self.fuse_gn or out_f32 or self._gn_slots >= 510 or self._gn_state is None:
             return False
         op = _lib.AdkOp()
         op.kind, op.dtype, op.B, op.L, op.P = _lib.OP_CONV, self.adk_dtype, self.B, x.L, self.P

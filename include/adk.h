@@ -84,11 +84,11 @@ enum {
                                    (zero beyond Cout), f0 = eps, ADK_FLAG_GELU selects the activation, `residual` is added
                                    AFTER norm + activation, partials_out (optional, residual form only) = statistics of y.
                                    aux1 = workspace of B * tiles-per-sample * 16 bytes, any contents, may be shared by the
-                                   fused convs of a stream; aux0 = uint32 words {epoch base, error, counters[4095]}, 16 KiB,
+                                   fused convs of a stream; aux0 = uint32 words {epoch base, error, counters[8][512]}, 16 KiB + 8,
                                    zero-initialised ONCE: adk_step_advance on the epoch base once per forward (before the
-                                   first fused conv), every fused conv of the forward with its own i1 = slot in [0, 4095),
-                                   every one of them run exactly once per forward (tiles are handed out by counters[slot],
-                                   which grows by the tile count per forward).  The error word becomes non-zero if a tile
+                                   first fused conv), every fused conv of the forward with its own i1 = slot in [0, 511),
+                                   every one of them run exactly once per forward (tiles are handed out, one list per XCD,
+                                   by counters[xcd][slot], which grow by a fixed amount per forward).  The error word becomes non-zero if a tile
                                    waited in vain for its sample's other tiles or the counters are out of step.
                                    Only where adk_conv_gn_fusable(). */
 

@@ -78,12 +78,20 @@ def run(cin, L, B=16, res=False):
     for nm, v in (("start", start), ("K end", kend), ("published", pub), ("wait over", waited), ("end", end)):
         print(f"  one CU, first 10 blocks, {nm:10s}:", np.round(v[o], 1))
     print("  their tickets / samples:", ticket[o], ticket[o] // npb)
-    for s in (0, 1, 2, B - 1):
+    for s in sorted({0, min(1, B - 1), min(2, B - 1), B - 1}):
         q = ticket // npb == s
         print(f"  sample {s}: starts {start[q].min():.1f}..{start[q].max():.1f}, published {pub[q].min():.1f}..{pub[q].max():.1f}, ends {end[q].min():.1f}..{end[q].max():.1f}")
 
 
-run(128, 65536)
-run(128, 65536, res=True)
-run(256, 16384)
-run(512, 4096)
+if "--solo" in sys.argv:      # K loop of a block that has its CU to itself (256 blocks) / shares it with one other (512)
+    run(128, 65536, B=1)
+    run(128, 65536, B=2)
+    run(256, 16384, B=2)
+    run(256, 16384, B=4)
+    run(512, 4096, B=4)
+    run(512, 4096, B=8)
+else:
+    run(128, 65536)
+    run(128, 65536, res=True)
+    run(256, 16384)
+    run(512, 4096)

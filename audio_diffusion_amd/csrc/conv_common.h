@@ -38,7 +38,14 @@ template <> struct Mma<bf16_t> {
 template <> struct Mma<f16_t> {
     typedef f16x8 Frag;
     static __device__ __forceinline__ void run(const Frag& a, const Frag& b, f32x16& c) {
+#ifdef ADK_ABL_MFMA16      /* timing experiment (wrong results): the same FLOPs as two 16x16x32 MFMAs on slices of the accumulator */
+        f32x4 c0 = __builtin_shufflevector(c, c, 0, 1, 2, 3), c1 = __builtin_shufflevector(c, c, 4, 5, 6, 7);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
+        c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3]; c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
+#else
         c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
     }
 };
 template <> struct Mma<float> {

@@ -20,6 +20,9 @@
 //     channel 32 i + 16 ci + 4 q + e, position 32 j + 16 pj + l15 (conv_epilogue_gn's M16 branch).
 #pragma once
 #include <type_traits>
+#ifndef ADK_TIE_STEPS
+#define ADK_TIE_STEPS 1
+#endif
 #include "conv_mfma_kernels.h"
 
 template <typename T> struct Mma16;
@@ -47,6 +50,27 @@ template <int G> __device__ __forceinline__ void mma16_sub(const typename Mma16<
     f32x4 s = __builtin_shufflevector(c, c, 4 * G, 4 * G + 1, 4 * G + 2, 4 * G + 3);
     s = Mma16<bf16_t>::run(a, b, s);
     c[4 * G] = s[0]; c[4 * G + 1] = s[1]; c[4 * G + 2] = s[2]; c[4 * G + 3] = s[3];
+}
+
+// Fragment reads and their waits are inline asm: the compiler otherwise gathers the reads into groups right in front of an
+// lgkmcnt(0) (three exposed LDS round trips per phase in its schedule).  asm volatile statements keep their order, LDS
+// returns in order, so each wait is a COUNTED lgkmcnt(N) - N = reads issued after the fragment it is for - and names the
+// registers it releases (a data dependency the consuming MFMAs cannot be moved across).
+template <int OFF, typename Frag> __device__ __forceinline__ void lds_read128(Frag& r, unsigned addr) {
+    static_assert(sizeof(Frag) == 16 && OFF >= 0 && OFF < 65536, "one ds_read_b128, immediate offset");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N, typename Frag> __device__ __forceinline__ void lds_wait(Frag& f) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N) : "memory");
+}
+template <int N, typename Frag> __device__ __forceinline__ void lds_wait_after(Frag& f, f32x16& prev) {   // ... and after the MFMAs into `prev` are issued
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f), "+v"(prev) : "n"(N) : "memory");
+}
+template <int N, typename Frag> __device__ __forceinline__ void lds_wait(Frag& f, Frag (&g)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(f), "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]) : "n"(N) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr32(const unsigned char* p) {
+    return (unsigned)(size_t)((const __attribute__((address_space(3))) unsigned char*)p);
 }
 
 template <typename T, int TAPS, int WCO, int WPOS, int TCO, int TPOS, bool KEEP = false>
@@ -175,12 +199,9 @@ __device__ __forceinline__ ConvTileId conv_tile_mainloop16(const ConvArgs& a, co
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const unsigned char* wt = ws + wlane;
-        const unsigned char* xt = xs + xlane(0);
-#pragma unroll
-        for (int x = 0; x < NA; ++x) aq[0][x] = *reinterpret_cast<const Frag*>(wt + x * 1024);
-#pragma unroll
-        for (int y = 0; y < 3; ++y) bq[y] = *reinterpret_cast<const Frag*>(xt + y * 1024);
+        const unsigned wt = lds_addr32(ws + wlane), xt = lds_addr32(xs + xlane(0));
+        lds_read128<0>(aq[0][0], wt); lds_read128<1024>(aq[0][1], wt); lds_read128<2048>(aq[0][2], wt); lds_read128<3072>(aq[0][3], wt);
+        lds_read128<0>(bq[0], xt); lds_read128<1024>(bq[1], xt); lds_read128<2048>(bq[2], xt);
     }
 
     auto phase = [&](auto tapc, auto parc, const int kc, const bool last) {
@@ -195,22 +216,25 @@ __device__ __forceinline__ ConvTileId conv_tile_mainloop16(const ConvArgs& a, co
         if (g + K < total) issue_unit(g + K);
         constexpr int nt = (TAP_ + 1) % TAPS;
         const int nkc = kc + (TAP_ + 1 == TAPS ? 1 : 0);
-        const unsigned char* xt_c = xs + (kc % RX) * XBYTES + xlane(TAP_);
-        const unsigned char* xt_n = xs + (nkc % RX) * XBYTES + xlane(nt);     // after the tile's last unit: a stale slot, discarded
-        const unsigned char* wt_n = ws + ((g + 1) % RW) * WBYTES + wlane;
-#pragma unroll
-        for (int y = 0; y < NB; ++y) {
-            if (y + 3 < NB) bq[(y + 3) & 3] = *reinterpret_cast<const Frag*>(xt_c + (y + 3) * 1024);
-            else bq[(y + 3) & 3] = *reinterpret_cast<const Frag*>(xt_n + (y + 3 - NB) * 1024);
-            if (y < NA) aq[PAR_ ^ 1][y] = *reinterpret_cast<const Frag*>(wt_n + y * 1024);
-#pragma unroll
-            for (int x = 0; x < NA; ++x) {
-                if ((x & 1) == 0 && (y & 1) == 0) mma16_sub<0>(aq[PAR_][x], bq[y & 3], acc[x >> 1][y >> 1]);
-                if ((x & 1) == 0 && (y & 1) == 1) mma16_sub<1>(aq[PAR_][x], bq[y & 3], acc[x >> 1][y >> 1]);
-                if ((x & 1) == 1 && (y & 1) == 0) mma16_sub<2>(aq[PAR_][x], bq[y & 3], acc[x >> 1][y >> 1]);
-                if ((x & 1) == 1 && (y & 1) == 1) mma16_sub<3>(aq[PAR_][x], bq[y & 3], acc[x >> 1][y >> 1]);
-            }
-        }
+        const unsigned xt_c = lds_addr32(xs + (kc % RX) * XBYTES + xlane(TAP_));
+        const unsigned xt_n = lds_addr32(xs + (nkc % RX) * XBYTES + xlane(nt));     // after the tile's last unit: a stale slot, discarded
+        const unsigned wt_n = lds_addr32(ws + ((g + 1) % RW) * WBYTES + wlane);
+        // step y: wait for B[y] (requested three steps ago; at y = 0 also this unit's A fragments), request B[y+3] (of the
+        // next unit from y = 5) and, in the first four steps, the next unit's A[y]; then the four MFMAs A[0..3] x B[y].
+        // Reads per step: 2, 2, 2, 2, 1, 1, 1, 1 -> reads younger than B[y] when step y starts: 2, 3, 4, 4, 4, 3, 2, 2.
+#define ADK_STEP(Y_, NYOUNGER_)                                                                              \
+        if constexpr ((Y_) == 0) lds_wait<NYOUNGER_>(bq[0], aq[PAR_]);                                       \
+        else if constexpr (ADK_TIE_STEPS) lds_wait_after<NYOUNGER_>(bq[(Y_) & 3], acc[1][((Y_) - 1) >> 1]);  \
+        else lds_wait<NYOUNGER_>(bq[(Y_) & 3]);                                                              \
+        if constexpr ((Y_) + 3 < NB) lds_read128<((Y_) + 3) * 1024>(bq[((Y_) + 3) & 3], xt_c);               \
+        else lds_read128<((Y_) + 3 - NB) * 1024>(bq[((Y_) + 3) & 3], xt_n);                                  \
+        if constexpr ((Y_) < NA) lds_read128<((Y_) & 3) * 1024>(aq[PAR_ ^ 1][(Y_) & 3], wt_n);               \
+        mma16_sub<((Y_) & 1)>(aq[PAR_][0], bq[(Y_) & 3], acc[0][(Y_) >> 1]);                                 \
+        mma16_sub<2 + ((Y_) & 1)>(aq[PAR_][1], bq[(Y_) & 3], acc[0][(Y_) >> 1]);                             \
+        mma16_sub<((Y_) & 1)>(aq[PAR_][2], bq[(Y_) & 3], acc[1][(Y_) >> 1]);                                 \
+        mma16_sub<2 + ((Y_) & 1)>(aq[PAR_][3], bq[(Y_) & 3], acc[1][(Y_) >> 1]);
+        ADK_STEP(0, 2) ADK_STEP(1, 3) ADK_STEP(2, 4) ADK_STEP(3, 4) ADK_STEP(4, 4) ADK_STEP(5, 3) ADK_STEP(6, 2) ADK_STEP(7, 2)
+#undef ADK_STEP
     };
     auto chunk = [&](auto parc, const int kc) {
         constexpr int P0 = decltype(parc)::value;

@@ -20,9 +20,6 @@
 //     channel 32 i + 16 ci + 4 q + e, position 32 j + 16 pj + l15 (conv_epilogue_gn's M16 branch).
 #pragma once
 #include <type_traits>
-#ifndef ADK_TIE_STEPS
-#define ADK_TIE_STEPS 1
-#endif
 #include "conv_mfma_kernels.h"
 
 template <typename T> struct Mma16;
@@ -63,9 +60,13 @@ template <int OFF, typename Frag> __device__ __forceinline__ void lds_read128(Fr
 template <int N, typename Frag> __device__ __forceinline__ void lds_wait(Frag& f) {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N) : "memory");
 }
-template <int N, typename Frag> __device__ __forceinline__ void lds_wait_after(Frag& f, f32x16& prev) {   // ... and after the MFMAs into `prev` are issued
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f), "+v"(prev) : "n"(N) : "memory");
-}
+// (NEVER pass an accumulator through such an asm to order it after the MFMAs that write it: a version of this loop tied
+// each wait to the previous step's accumulator tuple as an in/out operand.  The compiler then takes the asm - not the
+// MFMA still in flight - for the producer of those registers, its hazard recogniser stops inserting the wait states an
+// MFMA needs before it reads, as SrcC, registers that overlap but do not coincide with an in-flight MFMA's destination,
+// and whole samples came out different from run to run wherever the register assignment had such a pair: on the odd
+// chunk's tail of the unrolled loop, under load only.  Found by tools/soak_fused.py, isolated with tools/bisect_plan.py
+// and tools/rerun_fused.py.)
 template <int N, typename Frag> __device__ __forceinline__ void lds_wait(Frag& f, Frag (&g)[4]) {
     asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(f), "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]) : "n"(N) : "memory");
 }
@@ -223,9 +224,7 @@ __device__ __forceinline__ ConvTileId conv_tile_mainloop16(const ConvArgs& a, co
         // next unit from y = 5) and, in the first four steps, the next unit's A[y]; then the four MFMAs A[0..3] x B[y].
         // Reads per step: 2, 2, 2, 2, 1, 1, 1, 1 -> reads younger than B[y] when step y starts: 2, 3, 4, 4, 4, 3, 2, 2.
 #define ADK_STEP(Y_, NYOUNGER_)                                                                              \
-        if constexpr ((Y_) == 0) lds_wait<NYOUNGER_>(bq[0], aq[PAR_]);                                       \
-        else if constexpr (ADK_TIE_STEPS) lds_wait_after<NYOUNGER_>(bq[(Y_) & 3], acc[1][((Y_) - 1) >> 1]);  \
-        else lds_wait<NYOUNGER_>(bq[(Y_) & 3]);                                                              \
+        if constexpr ((Y_) == 0) lds_wait<NYOUNGER_>(bq[0], aq[PAR_]); else lds_wait<NYOUNGER_>(bq[(Y_) & 3]);   \
         if constexpr ((Y_) + 3 < NB) lds_read128<((Y_) + 3) * 1024>(bq[((Y_) + 3) & 3], xt_c);               \
         else lds_read128<((Y_) + 3 - NB) * 1024>(bq[((Y_) + 3) & 3], xt_n);                                  \
         if constexpr ((Y_) < NA) lds_read128<((Y_) & 3) * 1024>(aq[PAR_ ^ 1][(Y_) & 3], wt_n);               \
@@ -253,6 +252,15 @@ __device__ __forceinline__ ConvTileId conv_tile_mainloop16(const ConvArgs& a, co
         chunk(std::integral_constant<int, 1>(), kc + 1);
     }
     if (kc < a.nchunks) chunk(std::integral_constant<int, 0>(), kc);
+    // The last phase has requested fragments of a unit that does not exist (7 reads of stale LDS).  Nobody consumes them, but
+    // they still WRITE their registers when they return, and the compiler - which sees asm outputs that are never used -
+    // is free to give those registers to other values at once.  Keep every fragment register occupied until the reads
+    // have returned (seen as run-to-run differences of a 100-step sample before this was here).
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(aq[0][0]), "+v"(aq[0][1]), "+v"(aq[0][2]), "+v"(aq[0][3]), "+v"(aq[1][0]), "+v"(aq[1][1]), "+v"(aq[1][2]),
+                   "+v"(aq[1][3]), "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3])
+                 :
+                 : "memory");
     __syncthreads();      // all fragment reads done before the epilogue reuses LDS
     ADK_TS(1)
     ConvTileId id;

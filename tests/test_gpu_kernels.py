@@ -531,6 +531,54 @@ def test_conv_groupnorm_gelu_fused(env, dt, case):
         assert int(state[1].item()) != 0
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("cin", [32, 96, 128])
+def test_fused_conv_reruns_identical_with_blocks_cycling(env, dt, cin):
+    """B = 16 at L = 65536: 4096 tiles on 512 resident slots, so blocks start beside blocks that are in any phase of their
+    life.  Odd channel-chunk counts (Cin = 32: the model's first conv; 96) run the tail of the 16x16x32 K loop, which is
+    unrolled over chunk pairs.  A build whose inline-asm waits also named the accumulators gave different SAMPLES from run
+    to run exactly here (missing MFMA wait states, conv_mainloop16.h) while every two-sample test passed.  Twelve launches
+    must agree bit for bit, and with the fp32 composition of the ATen ops."""
+    lib, _lib, layout, dev = env
+    dtype, adk, tol = DT[dt]
+    B, L, Cout, taps, P = 16, 65536, 128, 5, 2
+    cb = layout.chunk(dtype)
+    g = torch.Generator().manual_seed(7 + cin)
+    x = torch.randn(B, cin, L, generator=g)
+    w = torch.randn(Cout, cin, taps, generator=g) / (cin * taps) ** 0.5
+    bias = torch.randn(Cout, generator=g) * 0.3
+    gamma, beta = torch.randn(Cout, generator=g) * 0.5 + 1.0, torch.randn(Cout, generator=g) * 0.2
+    xd = layout.to_cpl(x.to(dev), dtype, P)
+    wd = pack_w(w, cin, Cout, cb, dtype, dev)
+    bd, gd, btd = bias.to(dev), gamma.to(dev), beta.to(dev)
+    state = torch.zeros(4096 + 4, dtype=torch.int32, device=dev)
+    ws = torch.zeros(B * 512 * 2, dtype=torch.int64, device=dev)
+    op = _lib.AdkOp()
+    op.kind, op.dtype, op.flags = _lib.OP_CONV, adk, _lib.FLAG_FUSE_GN | _lib.FLAG_GELU
+    op.B, op.L, op.P, op.Cin, op.Cout, op.CoutPad, op.taps, op.i1, op.f0 = B, L, P, cin, Cout, Cout, taps, 5, 1e-5
+    op.x, op.w, op.bias, op.gamma, op.beta = xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), gd.data_ptr(), btd.data_ptr()
+    op.aux0, op.aux1 = state.data_ptr(), ws.data_ptr()
+    first = None
+    for it in range(12):
+        yd = torch.full((Cout // cb, B, L + 2 * P, cb), 3.0, dtype=dtype, device=dev)
+        op.y = yd.data_ptr()
+        assert lib.adk_step_advance(state.data_ptr(), sp()) == 0
+        assert lib.adk_run_plan(C.byref(op), 1, sp()) == 0, lib.adk_last_error()
+        torch.cuda.synchronize()
+        assert int(state[1].item()) == 0
+        if first is None:
+            first = yd
+        else:
+            assert torch.equal(first.view(torch.int16), yd.view(torch.int16)), f"launch {it} differs from launch 0"
+    ref = F.gelu(F.group_norm(F.conv1d(quant(x[:2], dtype), quant(w, dtype), bias, padding=P), 1, gamma, beta, 1e-5))
+    got = layout.from_cpl(first, Cout)[:, :, P:P + L].float().cpu()
+    assert rel_err(got[:2], ref) <= tol
+    # every sample sees the same weights: per-sample error against its own reference for two more samples, spread out
+    for b in (7, 15):
+        rb = F.gelu(F.group_norm(F.conv1d(quant(x[b:b + 1], dtype), quant(w, dtype), bias, padding=P), 1, gamma, beta, 1e-5))
+        assert rel_err(got[b:b + 1], rb) <= tol
+
+
 def test_conv_groupnorm_fusion_argument_checks(env):
     lib, _lib, layout, dev = env
     op = _lib.AdkOp()

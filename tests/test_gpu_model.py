@@ -166,6 +166,26 @@ def test_full_model_first_call_and_10_steps():
     assert snr_db(predb, ref) >= 50.0                    # measured 61 dB; 60 dB is the fp32 bar
 
 
+def test_full_model_calls_identical_at_batch_16():
+    """The configs[1] model at the bench batch (every long level cycles 8 generations of blocks through the GPU): five
+    denoiser calls on the same input must agree bit for bit - a whole-sample difference here is how a missing MFMA wait
+    state in the fused conv + GroupNorm kernel showed (tests/test_gpu_kernels.py::test_fused_conv_reruns_identical_...)."""
+    import audio_diffusion_amd as A
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    m = A.DiffusionAttnUnet1D(n_attn_layers=4).to(dev).eval()
+    m.compute_dtype = torch.float16
+    x = torch.randn(16, 2, 65536, device=dev)
+    t = torch.full((16,), 0.5, device=dev)
+    with torch.no_grad():
+        ref = m(x, t).clone()
+        for _ in range(4):
+            assert torch.equal(m(x, t), ref)
+    assert torch.isfinite(ref).all()
+    plan = next(iter(m._plans.values()))
+    assert plan.gn_error() == 0
+
+
 def test_crash_schedule_sampler_and_int16_output_stage():
     """the training demos' sampler (train_uncond.py:45-86: crash-warped timesteps) against the output of
     the reference's own function definitions (tests/golden/glue.npz, tools/make_goldens.py tier G), and the int16

@@ -128,14 +128,17 @@ __device__ __forceinline__ ConvTileId conv_tile_mainloop16(const ConvArgs& a, co
     const int total = a.nchunks * TAPS;
 
     // bias of this lane's channels: 32 i + 16 ci + 4 q .. + 3; requested before the first LDS-DMA unit (conv_bias_fetch)
+    // The loads are UNCONDITIONAL (a conv without bias reads gamma - always there in this kernel, same extent - and
+    // discards it): loads inside a branch leave the compiler unable to count them, and it then guards the accumulator
+    // initialisation with a vmcnt(0) of its own, which also drains the prefetched units 1..K-1.
     float4 bv[TCO][2];
     if constexpr (!KEEP) {
+        const float* bsrc = a.bias ? a.bias : a.gamma;
 #pragma unroll
         for (int i = 0; i < TCO; ++i)
 #pragma unroll
             for (int ci = 0; ci < 2; ++ci)
-                bv[i][ci] = a.bias ? *reinterpret_cast<const float4*>(a.bias + cobase + (wco * TCO + i) * 32 + 16 * ci + 4 * q)
-                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+                bv[i][ci] = *reinterpret_cast<const float4*>(bsrc + cobase + (wco * TCO + i) * 32 + 16 * ci + 4 * q);
     }
 
     unsigned xsrc[XI], wsrc[WI];
@@ -154,14 +157,14 @@ __device__ __forceinline__ ConvTileId conv_tile_mainloop16(const ConvArgs& a, co
 
     // (the 32-bit per-lane offsets pass through an opaque asm at every use: the 64-bit source addresses are then formed
     // where they are used instead of living - and spilling - as seven loop-invariant register pairs)
-    auto issue_unit = [&](int u) {               // u = kc * TAPS + tap, wave-uniform
+    auto issue_unit = [&](int u, auto opaque) {  // u = kc * TAPS + tap, wave-uniform
         const int kc = u / TAPS, tap = u - kc * TAPS;
         if (tap == 0) {
             const unsigned char* xb = xg + kc * xplane;
             unsigned char* dst = xs + (kc % RX) * XBYTES + wave * 1024;
 #pragma unroll
             for (int j = 0; j < XI; ++j) {
-                asm volatile("" : "+v"(xsrc[j]));
+                if constexpr (decltype(opaque)::value) asm volatile("" : "+v"(xsrc[j]));
                 glds16(xb + xsrc[j], dst + j * (NW * 1024));
             }
         }
@@ -169,7 +172,7 @@ __device__ __forceinline__ ConvTileId conv_tile_mainloop16(const ConvArgs& a, co
         unsigned char* dst = ws + (u % RW) * WBYTES + wave * 1024;
 #pragma unroll
         for (int j = 0; j < WI; ++j) {
-            asm volatile("" : "+v"(wsrc[j]));
+            if constexpr (decltype(opaque)::value) asm volatile("" : "+v"(wsrc[j]));
             glds16(wb + wsrc[j], dst + j * (NW * 1024));
         }
     };
@@ -183,21 +186,34 @@ __device__ __forceinline__ ConvTileId conv_tile_mainloop16(const ConvArgs& a, co
     // prologue: units 0..K-1 in flight, wait for unit 0, unit 0's A fragments and first three B fragments
 #pragma unroll
     for (int u = 0; u < K; ++u)
-        if (u < total) issue_unit(u);
+        if (KEEP ? u < total : true) issue_unit(u, std::false_type());   // a conv's K loop has >= TAPS >= K units; unconditional,
+                                                                         // so that the compiler can COUNT them (bias wait below)
     {
         constexpr int n0 = []() { int n = 0; for (int u = 1; u < K; ++u) n += WI + (u % TAPS == 0 ? XI : 0); return n; }();
-        if (total >= K) wait_vmcnt_visible<n0>(); else wait_vmcnt_visible<0>();
+        if (!KEEP || total >= K) wait_vmcnt_visible<n0>(); else wait_vmcnt_visible<0>();
         if constexpr (!KEEP) {
+            const float keep = a.bias ? 1.f : 0.f;           // applied only now: the values must not be touched before the wait above
 #pragma unroll
             for (int i = 0; i < TCO; ++i)
 #pragma unroll
                 for (int j = 0; j < TPOS; ++j)
 #pragma unroll
                     for (int G = 0; G < 4; ++G) {
-                        acc[i][j][4 * G] = bv[i][G >> 1].x; acc[i][j][4 * G + 1] = bv[i][G >> 1].y;
-                        acc[i][j][4 * G + 2] = bv[i][G >> 1].z; acc[i][j][4 * G + 3] = bv[i][G >> 1].w;
+                        acc[i][j][4 * G] = bv[i][G >> 1].x * keep; acc[i][j][4 * G + 1] = bv[i][G >> 1].y * keep;
+                        acc[i][j][4 * G + 2] = bv[i][G >> 1].z * keep; acc[i][j][4 * G + 3] = bv[i][G >> 1].w * keep;
                     }
         }
+#ifndef ADK_EXP_NO_ACC_PIN
+        // pin the bias -> accumulator copies HERE: sunk below the asm reads, the compiler guards them with a vmcnt(0) of its
+        // own (it cannot count across inline asm), which also drains units 1..K-1.  No MFMA is in flight yet, so naming
+        // the accumulators in an asm is harmless at this one place (see the note at lds_wait).
+        if constexpr (!KEEP) {
+#pragma unroll
+            for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                for (int j = 0; j < TPOS; ++j) asm volatile("" : "+v"(acc[i][j]));
+        }
+#endif
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const unsigned wt = lds_addr32(ws + wlane), xt = lds_addr32(xs + xlane(0));
@@ -214,7 +230,7 @@ __device__ __forceinline__ ConvTileId conv_tile_mainloop16(const ConvArgs& a, co
         if (last) wait_vmcnt<n_last>(); else wait_vmcnt<n_mid>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (g + K < total) issue_unit(g + K);
+        if (g + K < total) issue_unit(g + K, std::true_type());
         constexpr int nt = (TAP_ + 1) % TAPS;
         const int nkc = kc + (TAP_ + 1 == TAPS ? 1 : 0);
         const unsigned xt_c = lds_addr32(xs + (kc % RX) * XBYTES + xlane(TAP_));

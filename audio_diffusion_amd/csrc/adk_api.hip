@@ -12,6 +12,7 @@ int conv_partials_count(const adk_op& op);
 int conv_postile(const adk_op& op);
 int conv_cotile_used(const adk_op& op);
 int conv_gn_check(const adk_op& op, const char** why);
+int conv_gn_fusable_here(const adk_op& op);
 int launch_gn(const adk_op& op, hipStream_t st, bool apply);
 int gn_partials_count(int dtype, int C, int L);
 int launch_fir(const adk_op& op, hipStream_t st, bool up);
@@ -297,7 +298,7 @@ int adk_conv_postile(const adk_op* op) { return (op && op->kind == ADK_OP_CONV) 
 int adk_conv_cotile(int dtype, int Cout, int L) { (void)dtype; (void)L; return conv_cotile(Cout); }
 
 int adk_sizeof_op(void) { return (int)sizeof(adk_op); }
-int adk_conv_gn_fusable(const adk_op* op) { return (op && op->kind == ADK_OP_CONV) ? conv_gn_check(*op, nullptr) : 0; }
+int adk_conv_gn_fusable(const adk_op* op) { return (op && op->kind == ADK_OP_CONV) ? conv_gn_fusable_here(*op) : 0; }
 
 static adk_op zero_op(int kind, int dtype)
 {

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/adk.h"
 
 typedef __bf16 bf16_t;
@@ -207,4 +208,16 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
     const unsigned q = nblk >> 3, r = nblk & 7u, xcd = bid & 7u, slot = bid >> 3;
     const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + slot;
+}
+
+// One-time, PER-DEVICE opt-in to more than 64 KiB of dynamic LDS (hipFuncSetAttribute is kept per device, and the
+// library is re-entrant): bit d of `done` = set on device d.  A race between two first callers sets it twice, harmlessly.
+static inline int adk_lds_optin(std::atomic<unsigned long long>& done, const void* fn, size_t bytes)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ADK_ELAUNCH;
+    if ((done.load(std::memory_order_acquire) >> dev) & 1ull) return ADK_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return ADK_ELAUNCH;
+    done.fetch_or(1ull << dev, std::memory_order_release);
+    return ADK_OK;
 }

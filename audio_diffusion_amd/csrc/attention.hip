@@ -540,12 +540,8 @@ static int launch_attn_mfma_f32(const adk_op& op, hipStream_t st)
     a.heads = op.Cin / D; a.ntq = (op.L + 32 * TQ - 1) / (32 * TQ);
     a.nitems = op.B * a.heads * a.ntq;
     const size_t lds = (size_t)4 * 2 * 32 * (D + 8) * 4;
-    static bool attr_set = false;             // d = 64: 72 KiB of dynamic LDS needs the opt-in, once per kernel
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mfma_f32_kernel<TQ, D>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ADK_ELAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_set{0};   // d = 64: 72 KiB of dynamic LDS needs the opt-in, once per kernel and device
+    if (adk_lds_optin(attr_set, reinterpret_cast<const void*>(&attn_mfma_f32_kernel<TQ, D>), lds)) return ADK_ELAUNCH;
     hipLaunchKernelGGL((attn_mfma_f32_kernel<TQ, D>), dim3((a.nitems + 3) / 4), dim3(256), lds, st, a);
     return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
 }
@@ -788,12 +784,9 @@ static int launch_attn_qkv(const adk_op& op, hipStream_t st)
     a.eps = op.f0; a.count = (double)op.i2 * (double)op.L;
     const int npt = (op.L + 31) / 32;
     const size_t lds = (size_t)3 * npt * 2048 + (npt <= 2 ? (size_t)4 * 3 * 2 * 4 * 64 * 16 : 0);   // + the k-split partials
-    static bool attr_set = false;             // > 64 KiB of dynamic LDS needs the opt-in, once per kernel
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_qkv_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                3 * 2 * 2048 + 4 * 3 * 2 * 4 * 64 * 16) != hipSuccess) return ADK_ELAUNCH;
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_set{0};   // > 64 KiB of dynamic LDS needs the opt-in, once per kernel and device
+    if (adk_lds_optin(attr_set, reinterpret_cast<const void*>(&attn_qkv_kernel<T>), (size_t)3 * 2 * 2048 + 4 * 3 * 2 * 4 * 64 * 16))
+        return ADK_ELAUNCH;
     hipLaunchKernelGGL((attn_qkv_kernel<T>), dim3(op.B * a.heads), dim3(256), lds, st, a);
     return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
 }

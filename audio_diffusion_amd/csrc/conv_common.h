@@ -117,3 +117,4 @@ int launch_conv_ksplit(const adk_op& op, hipStream_t st);
 int launch_conv_ext(const adk_op& op, hipStream_t st);      // conv_mfma_ext.hip
 int launch_conv_gn(const adk_op& op, hipStream_t st);       // conv_mfma_gn.hip
 int conv_gn_check(const adk_op& op, const char** why);      // host-only: can this conv op run with ADK_FLAG_FUSE_GN?
+int gn_device_ok(const char** why, bool may_probe = true);                          // does the current device deal workgroups evenly to 8 XCDs (probed once)?

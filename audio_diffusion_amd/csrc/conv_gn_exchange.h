@@ -36,6 +36,11 @@ __device__ __forceinline__ void gn_gather(const ConvArgs& a, int b, unsigned epo
 #pragma unroll
     for (int k = 0; k < 16; ++k)
         if (lane + 64 * k >= ng) { x[k] = (unsigned long long)epoch << 32; have |= 1u << k; }      // value +0.0
+    // A launch whose error word is already set (an earlier wait of this forward ran out, or the ticket counters are out of
+    // step) does not wait again: one poll, then on with what is there.  The forward's output is discarded by the host
+    // anyway (the word is sticky until the host clears it), so a mis-stepped run costs ONE bounded wait in all, not one per
+    // resident block per launch.  The word is read with the first poll's loads and again every 64 polls.
+    unsigned limit = __hip_atomic_load((gu32*)(a.gn_err), ADK_RLX_AGENT) ? 1u : GN_SPIN_LIMIT;
     for (unsigned spins = 0;;) {
         unsigned long long v[16];
 #pragma unroll
@@ -45,9 +50,12 @@ __device__ __forceinline__ void gn_gather(const ConvArgs& a, int b, unsigned epo
         for (int k = 0; k < 16; ++k)
             if ((unsigned)(v[k] >> 32) == epoch) { x[k] = v[k]; have |= 1u << k; }
         if (__all(have == 0xffffu)) break;
-        if (++spins >= GN_SPIN_LIMIT) {               // bounded: a block that is not resident must not hang the GPU
-            // 0x6sssbbb: which op (slot) and which sample ran out of patience
-            if (lane == 0) __hip_atomic_store((gu32*)(a.gn_err), 0x60000000u | (a.gn_slot << 12) | ((unsigned)b & 0xfffu), ADK_RLX_AGENT);
+        ++spins;
+        if ((spins & 63u) == 0u && spins < limit && __hip_atomic_load((gu32*)(a.gn_err), ADK_RLX_AGENT)) limit = spins;
+        if (spins >= limit) {                         // bounded: a block that is not resident must not hang the GPU
+            // 0x6sssbbb: which op (slot) and which sample ran out of patience (the FIRST such code of a forward stays)
+            if (lane == 0 && limit == GN_SPIN_LIMIT)
+                __hip_atomic_store((gu32*)(a.gn_err), 0x60000000u | (a.gn_slot << 12) | ((unsigned)b & 0xfffu), ADK_RLX_AGENT);
 #pragma unroll
             for (int k = 0; k < 16; ++k)
                 if (!(have & (1u << k))) x[k] = 0;

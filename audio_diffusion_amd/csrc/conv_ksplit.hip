@@ -361,20 +361,22 @@ static int launch_ks(const adk_op& op, hipStream_t st)
     if constexpr (TAPS != 1 && sizeof(T) == sizeof(TO)) {
         if (op.flags & ADK_FLAG_FUSE_GN) {
             const void* fn = reinterpret_cast<const void*>(&conv_ksplit_kernel<T, TO, TAPS, TCO, TPOS, DEPTH, true>);
-            static int cap[64];
+            static std::atomic<int> cap[64];                 // per device; atomic: the library is re-entrant
             int dev = 0;
             if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ADK_ELAUNCH;
-            if (!cap[dev]) {
+            int capd = cap[dev].load(std::memory_order_acquire);
+            if (!capd) {
                 int per_cu = 0, cus = 0;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess) return ADK_ELAUNCH;
                 if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return ADK_ELAUNCH;
                 const int lb = TCO * TPOS >= 4 ? 1 : 2;      // __launch_bounds__
                 if (per_cu > lb) per_cu = lb;
                 if (per_cu < 1 || cus < 1) return ADK_ELAUNCH;
-                cap[dev] = per_cu * cus;
+                capd = per_cu * cus;
+                cap[dev].store(capd, std::memory_order_release);
             }
-            if (a.npb > cap[dev]) return ADK_EINVAL;
-            a.gn_cap = (unsigned)cap[dev];
+            if (a.npb > capd) return ADK_EINVAL;
+            a.gn_cap = (unsigned)capd;
             // ticketed (more blocks than resident slots): spare blocks, see gn_spare; else every block is resident
             hipLaunchKernelGGL((conv_ksplit_kernel<T, TO, TAPS, TCO, TPOS, DEPTH, true>),
                                dim3(a.nblk > a.gn_cap ? a.gn_grid : a.nblk), dim3(256), lds, st, a);

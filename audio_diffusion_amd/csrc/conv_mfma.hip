@@ -12,6 +12,8 @@
 //   bf16: v_mfma_f32_32x32x16_bf16 (fp32 accumulate);  f32: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain).
 // Epilogue: + bias, (+ residual), per-tile (sum, sumsq) partials for the following GroupNorm(1,C)
 // (deterministic: fixed-order tree, no atomics), halo rows of the output zeroed by the edge tiles.
+#include <atomic>
+#include <mutex>
 #include "conv_mfma_kernels.h"
 
 void conv_fill_args(const adk_op& op, int BN, int BM, ConvArgs& a)
@@ -77,8 +79,90 @@ int conv_gn_check(const adk_op& op, const char** why)
     return 1;
 }
 
+// ---- does THIS device deal workgroups the way the fused launch's ticket lists assume? -----------------------------
+// The per-XCD ticket lists (conv_mfma_gn.inc) rest on dispatch behaviour HIP does not promise: 8 XCDs (HW_REG_XCC_ID in
+// 0..7), and a 1-D grid that is a multiple of 8 dealt round-robin so that exactly grid / 8 workgroups start on each XCD.
+// A partitioned GPU (CPX / DPX / QPX) or a part with another XCD count breaks both, and the counters would then run out
+// of step: every resident block would spin to its bound and the forward would be thrown away.  So before the first
+// fused launch on a device (adk_conv_gn_fusable at plan time, else the first launch) a probe kernel counts the
+// workgroups per XCC_ID for two grids; the fusion is refused on that device unless both came out exactly even.
+// Nothing is allocated: the counters are a file-scope __device__ array (address by hipGetSymbolAddress, per device).
+static __device__ __align__(64) unsigned g_xcd_probe[16];
+__global__ void xcd_probe_kernel(unsigned* out)
+{
+    if (threadIdx.x == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        atomicAdd(out + (xcc < 8u ? xcc : 8u), 1u);
+    }
+}
+
+int gn_device_ok(const char** why, bool may_probe)
+{
+    static std::atomic<int> state[64];            // 0 = not probed, 1 = ok, 2 = refused
+    static std::mutex mu;
+    static const char* reason[64];
+    const char* dummy;
+    if (!why) why = &dummy;
+    *why = "";
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { *why = "no current HIP device"; return 0; }
+    int s = state[dev].load(std::memory_order_acquire);
+    if (!s && !may_probe) { *why = "device not probed yet (call adk_conv_gn_fusable outside stream capture first)"; return 0; }
+    if (!s) {
+        std::lock_guard<std::mutex> lock(mu);
+        s = state[dev].load(std::memory_order_acquire);
+        if (!s) {
+            unsigned* ptr = nullptr;
+            unsigned host[16];
+            int cus = 0;
+            const char* r = nullptr;
+            bool transient = false;                // a failure that says nothing about the device (e.g. stream capture in progress)
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8 || cus % 8)
+                r = "the device's CU count is not a multiple of 8";
+            else if (hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(g_xcd_probe)) != hipSuccess || !ptr)
+                r = "hipGetSymbolAddress(g_xcd_probe) failed";
+            for (unsigned grid : {512u, 1032u}) {
+                if (r) break;
+                if (hipMemset(ptr, 0, sizeof host) != hipSuccess) { r = "probe: hipMemset failed (stream capture in progress?)"; transient = true; break; }
+                hipLaunchKernelGGL(xcd_probe_kernel, dim3(grid), dim3(64), 0, 0, ptr);
+                if (hipGetLastError() != hipSuccess || hipMemcpy(host, ptr, sizeof host, hipMemcpyDeviceToHost) != hipSuccess) {
+                    r = "probe: launch / copy failed (stream capture in progress?)"; transient = true; break;
+                }
+                for (int k = 0; k < 8; ++k)
+                    if (host[k] != grid / 8) r = "workgroups are not dealt evenly to 8 XCDs on this device (partition mode?)";
+                if (host[8]) r = "XCC_ID outside 0..7 on this device";
+            }
+            (void)hipGetLastError();
+            if (r && transient) { *why = r; return 0; }          // not cached: ask again outside the capture
+            reason[dev] = r;
+            s = r ? 2 : 1;
+            state[dev].store(s, std::memory_order_release);
+        }
+    }
+    if (s == 2) *why = reason[dev];
+    return s == 1;
+}
+
+// adk_conv_gn_fusable: the shape check and - for the pipelined kernel, whose ticket lists need it - the device probe
+int conv_gn_fusable_here(const adk_op& op)
+{
+    if (!conv_gn_check(op, nullptr)) return 0;
+    if (conv_tile(op).ksplit) return 1;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {      // host-only dry run of a plan (no GPU in this process):
+        (void)hipGetLastError();                                   // the shape answer; nothing can be launched here anyway,
+        return 1;                                                  // and every launch path probes its device itself
+    }
+    return gn_device_ok(nullptr, true);
+}
+
 int launch_conv_gn(const adk_op& op, hipStream_t st)
 {
+    // the probe synchronises: never start it from inside a stream capture (it would invalidate the capture)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    if (!gn_device_ok(nullptr, !capturing)) return ADK_EINVAL;
     if (op.dtype == ADK_F32) return launch_conv_gn_f32(op, st);
     if (op.dtype == ADK_F16) return launch_conv_gn_f16(op, st);
     return launch_conv_gn_bf16(op, st);

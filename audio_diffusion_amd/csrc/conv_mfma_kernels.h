@@ -550,13 +550,9 @@ static int launch_variant(const adk_op& op, hipStream_t st)
         constexpr int NW = WCO * WPOS;
         constexpr int XI = (BM + (TAPS - 1) * DIL + 16 * NW - 1) / (16 * NW);
         const size_t lds = (size_t)(TAPS == 1 ? K + 1 : 2) * XI * NW * 1024 + (size_t)(K + 1) * BN * 64;
-        static bool attr_set = false;             // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<EXT, T, TO, TAPS, WCO, WPOS, TCO, TPOS, DIL>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return ADK_ELAUNCH;
-            attr_set = true;
-        }
+        static std::atomic<unsigned long long> attr_set{0};   // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel and device
+        if (adk_lds_optin(attr_set, reinterpret_cast<const void*>(&conv_mfma_kernel<EXT, T, TO, TAPS, WCO, WPOS, TCO, TPOS, DIL>), lds))
+            return ADK_ELAUNCH;
         hipLaunchKernelGGL((conv_mfma_kernel<EXT, T, TO, TAPS, WCO, WPOS, TCO, TPOS, DIL>), dim3(a.nblk), dim3(NW * 64), lds, st, a);
     } else {
         const size_t lds = (size_t)((BM + (TAPS - 1) * DIL + 15) / 16) * 1024 + (size_t)TAPS * BN * 64;

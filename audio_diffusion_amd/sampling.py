@@ -12,7 +12,7 @@ import math
 import torch
 
 from . import _lib
-from .unet import DiffusionAttnUnet1D
+from .unet import DiffusionAttnUnet1D, FusedLaunchError
 
 
 def get_alphas_sigmas(t):
@@ -52,10 +52,6 @@ def step_coefficients(steps, eta, warp=None):
         else:
             tab[i, 6] = 1.0
     return tab
-
-
-class FusedLaunchError(RuntimeError):
-    """A fused conv + GroupNorm launch gave up waiting for a sample's statistics (error word of the plan's state)."""
 
 
 class _FusedSampler:
@@ -110,21 +106,27 @@ class _FusedSampler:
                 self._one_step(torch.cuda.current_stream(x.device).cuda_stream)
             self.graph = g
             # capture does not execute: state is still at step 0
-        if self.graph is not None:
-            for _ in range(self.steps):
+        sp = torch.cuda.current_stream(x.device).cuda_stream
+        for i in range(self.steps):
+            if self.graph is not None:
                 self.graph.replay()
-        else:
-            sp = torch.cuda.current_stream(x.device).cuda_stream
-            for _ in range(self.steps):
+            else:
                 self._one_step(sp)
+            if i == 0:
+                # The fused conv + GroupNorm launches wait, bounded, for the other tiles of a sample; a wait that ran out
+                # (or tickets out of step) leaves an error word instead of a hang.  A GPU that cannot run them (shared
+                # with another process, partitioned) shows it on the FIRST step: look now - one 4-byte read per
+                # sample() call - instead of paying the bounded waits of every remaining step first.
+                self._check()
         out = self.pred.clone()
-        # the fused conv + GroupNorm launches wait, bounded, for the other tiles of a sample; a wait that ran out (or
-        # tickets out of step) leaves an error word instead of a hang: never hand back audio computed past one
-        err = self.plan.gn_error()
+        self._check()                 # ... and never hand back audio computed past a flagged launch
+        return out
+
+    def _check(self):
+        err = self.plan.gn_error(clear=True)          # the host clears the sticky word where it raises
         if err:
             raise FusedLaunchError(f"libadk: a fused conv + GroupNorm launch flagged error {err:#x} during sample() "
                                    "(a tile waited in vain for its sample's statistics); the output was discarded")
-        return out
 
 
 @torch.no_grad()
@@ -226,12 +228,7 @@ def _sample(model, x, steps, eta, warp, extra_args):
     finally:
         if auto:
             model.compute_dtype = prev
-    if isinstance(model, DiffusionAttnUnet1D):       # same rule as the captured loop: no audio past a flagged fused launch
-        for p in list(model._plans.values()):
-            err = getattr(p, "plan", p).gn_error()
-            if err:
-                raise FusedLaunchError(f"libadk: a fused conv + GroupNorm launch flagged error {err:#x} during sample(); set "
-                                       "model.fuse_gn = False (GroupNorm as separate passes) if this GPU is shared")
+    # (a flagged fused launch inside model(...) has already raised or fallen back there: DiffusionAttnUnet1D.forward)
     return pred
 
 

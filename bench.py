@@ -17,8 +17,10 @@ A "step" is ONE pass of the hot path over one batch: ``sample(model, x[B,2,65536
 Rank 0 prints ONE JSON line.  Extra objects in it:
   roofline     : the dominant kernel (k=5 implicit-GEMM conv on MFMA), algorithmic FLOPs / HIP-event time,
                  measured live on the launch stream after the timed region (same plan, same buffers).
-  accuracy     : first denoiser call of the timed dtype against one fp32 call of this build on the same x
-                 (scale-relative max error max|a-b|/max|b| and relative L2), N = 1 only.
+  accuracy     : first denoiser call (t = 1) of the timed dtype on sample 0 against the CPU ORACLE's output for the
+                 same sample (oracle/unet_oracle.py, pinned by the reference's goldens; the cpu_baseline leg computes
+                 it as its warm-up call), scale-relative max error max|a-b|/max|b| and relative L2; the same against
+                 this build's own fp32 path as a secondary figure.  N = 1 only.
   fp32 / bf16  : ONE timed pass each of the same workload in the other dtypes of configs[1], N = 1 only.
   cpu_baseline : the repo's CPU oracle (plain PyTorch fp32, oracle/) timed on the host cores on a bounded
                  sample (B=1, a few denoiser calls), extrapolated to the 100-step metric.  Reported only.
@@ -93,28 +95,31 @@ def host_cpu_budget():
             "cgroup_quota": quota, "omp_num_threads": omp}
 
 
-def cpu_baseline(model, calls, budget):
-    """Time the CPU oracle (test infrastructure; never on the product path) on config 1's shape."""
+def cpu_baseline(model, calls, budget, x0):
+    """Time the CPU oracle (test infrastructure; never on the product path) on config 1's shape: ``x0`` = sample 0 of
+    the bench's own noise.  Returns (record, the oracle's output for (x0, t = 1)): the warm-up call IS step 0 of the
+    loop for that sample, and the accuracy object checks the GPU path against it."""
     import torch
     from oracle import unet_oracle as U, sampling_oracle as S
     threads = budget["threads"]
     torch.set_num_threads(threads)
     cfg = U.make_config(n_attn_layers=4)
     fn = U.make_model_fn(model.state_dict(), cfg)
-    torch.manual_seed(1)
-    x = torch.randn(1, 2, T)
+    x = x0.clone()
     t, _, _ = S.schedule(100)
-    fn(x, torch.ones(1) * t[0])                      # warm-up call (thread pool, allocator)
+    assert float(t[0]) == 1.0
+    v0 = fn(x, torch.ones(1) * t[0])                 # warm-up call (thread pool, allocator) = the oracle's step-0 output
     t0 = time.perf_counter()
     for i in range(calls):
         fn(x, torch.ones(1) * t[i])
     dt = (time.perf_counter() - t0) / calls
-    return {"value": (T / SAMPLE_RATE) / (dt * 100), "unit": "audio-s/s", "cores": threads, "kind": "port",
-            "host": {k: v for k, v in budget.items() if k != "threads"},
-            "cores_note": "threads = min(physical cores, scheduler affinity, cgroup CPU quota, the box's OMP_NUM_THREADS): "
-                          "the physical cores this job may actually use; host_logical / host_physical describe the whole machine",
-            "sample": f"B=1 x 2x{T}, {calls} denoiser calls timed ({dt:.3f} s/call), x100 for the 100-step loop; "
-                      "the DDIM update itself is <0.1% of a call"}
+    rec = {"value": (T / SAMPLE_RATE) / (dt * 100), "unit": "audio-s/s", "cores": threads, "kind": "port",
+           "host": {k: v for k, v in budget.items() if k != "threads"},
+           "cores_note": "threads = min(physical cores, scheduler affinity, cgroup CPU quota, the box's OMP_NUM_THREADS): "
+                         "the physical cores this job may actually use; host_logical / host_physical describe the whole machine",
+           "sample": f"B=1 x 2x{T} (sample 0 of the bench's noise), {calls} denoiser calls timed ({dt:.3f} s/call), x100 for "
+                     "the 100-step loop; the DDIM update itself is <0.1% of a call"}
+    return rec, v0.detach()
 
 
 def conv_roofline(model, B, dtype, dev, reps=3):
@@ -225,27 +230,44 @@ def _offset(ops, i):
     return ctypes.cast(ctypes.byref(ops, i * ctypes.sizeof(_lib.AdkOp)), ctypes.POINTER(_lib.AdkOp))
 
 
-def first_call_accuracy(model, x, dtype, dev):
-    """The timed dtype's first denoiser call (t = 1, what step 0 of the loop computes) against ONE fp32 call of this
-    build on the same x; per-sample work, so two samples stand for the batch."""
+def first_call_accuracy(model, x, dtype, dev, oracle_v0=None):
+    """The timed dtype's first denoiser call (t = 1, what step 0 of the loop computes).  Primary figure: sample 0 against
+    the CPU oracle's output for that sample (``oracle_v0``, from the cpu_baseline leg).  Secondary: two samples against
+    ONE fp32 call of this build on the same x (per-sample work, so two samples stand for the batch)."""
     import torch
     xs = x[:2].contiguous()
     tt = torch.ones(xs.shape[0], device=dev)
     prev = model.compute_dtype
     try:
         model.compute_dtype = torch.float32
-        ref = model(xs, tt).double()
+        own = model(xs, tt).double()
         model.compute_dtype = dtype
         got = model(xs, tt).double()
     finally:
         model.compute_dtype = prev
-    return {"metric": ERR_METRIC, "reference": "this build's fp32 path (held to <= 1e-4 of the reference by tests/test_gpu_model.py)",
-            "max_rel": float((got - ref).abs().max() / ref.abs().max()),
-            "rel_l2": float((got - ref).norm() / ref.norm()), "samples": int(xs.shape[0]),
-            "bound": 1e-2 if dtype != torch.float32 else 1e-4}
+    bound = 1e-2 if dtype != torch.float32 else 1e-4
+    own_rec = {"reference": "this build's fp32 path (held to <= 1e-4 of the reference by tests/test_gpu_model.py)",
+               "max_rel": float((got - own).abs().max() / own.abs().max()),
+               "rel_l2": float((got - own).norm() / own.norm()), "samples": int(xs.shape[0])}
+    if oracle_v0 is None:
+        return dict(own_rec, metric=ERR_METRIC, bound=bound, note="cpu_baseline leg skipped: no oracle output to compare with")
+    ref = oracle_v0.double().to(dev)
+    g0 = got[:1]
+    err = float((g0 - ref).abs().max() / ref.abs().max())
+    rec = {"metric": ERR_METRIC,
+           "reference": "oracle/unet_oracle.py: the CPU fp32 restatement of DiffusionAttnUnet1D.forward "
+                        "(decoders/diffusion_decoder.py:139-176), pinned by the reference's golden vectors "
+                        "(tests/test_oracle_golden.py); sample 0 of the bench's noise at t = 1",
+           "max_rel": err, "rel_l2": float((g0 - ref).norm() / ref.norm()), "samples": 1, "bound": bound,
+           "within_bound": bool(err <= bound), "vs_own_fp32": own_rec}
+    if dtype == torch.bfloat16:
+        rec["note"] = ("bf16 is a secondary record OUTSIDE north_star's 1e-2 bound (measured 1.1-1.3e-2: rounding only the MFMA "
+                       "operands to bf16 already costs 1.0-1.9e-2, tests/test_dtype_floor_cpu.py); f16, the reference's "
+                       "autocast dtype, is the default and the headline")
+    return rec
 
 
-def timed_pass(model, x, dtype, ddim_steps, dev):
+def timed_pass(model, x, dtype, ddim_steps, dev, oracle_v0=None):
     """ONE timed pass of the workload in another dtype (plan build, graph capture and one untimed pass first)."""
     import torch
     import audio_diffusion_amd as A
@@ -259,7 +281,7 @@ def timed_pass(model, x, dtype, ddim_steps, dev):
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
         assert torch.isfinite(out).all()
-        acc = first_call_accuracy(model, x, dtype, dev) if dtype != torch.float32 else None
+        acc = first_call_accuracy(model, x, dtype, dev, oracle_v0)
     finally:
         model.compute_dtype = prev
         for k in [k for k in model._plans if dtype in k]:         # release this dtype's arena
@@ -345,27 +367,34 @@ def main():
     lo, hi = D.shard_bounds(total, rank, world)
 
     if a.standin:
-        model, cpu = None, None
+        model = None
 
         def sampler(m, xx, steps, eta):
             return torch.tanh(xx * 3.0) + steps
     else:
         import audio_diffusion_amd as A
         model = build_model()
-        cpu = None
-        if rank == 0 and world == 1 and a.cpu_calls > 0:
-            cpu = cpu_baseline(model, a.cpu_calls, host_cpu_budget())
-        model = model.to(dev)
-        model.compute_dtype = dtype
-        model.fuse_gn = not a.no_fuse_gn
         sampler = A.sample
 
     # noise generated ONCE from a single CPU seed and sliced per rank: a sample's result does not depend on N
     g = torch.Generator().manual_seed(1)
     Tn = 64 if a.standin else T
     noise = torch.randn(total, 2, Tn, generator=g)
+    cpu = oracle_v0 = None
+    if not a.standin:
+        if rank == 0 and world == 1 and a.cpu_calls > 0:
+            cpu, oracle_v0 = cpu_baseline(model, a.cpu_calls, host_cpu_budget(), noise[0:1])
+        model = model.to(dev)
+        model.compute_dtype = dtype
+        model.fuse_gn = not a.no_fuse_gn
     x = noise[lo:hi].to(dev)
     del noise
+
+    # N > 1 runs configs[4] as written (global batch 256): say up front how long the requested passes will take
+    if world > 1 and rank == 0 and not a.standin:
+        est = (a.steps + a.warmup) * (hi - lo) * (T / SAMPLE_RATE) * a.ddim_steps / 100 / 15.0
+        print(f"[bench] {world} GPUs x {hi - lo} samples: about {est:.0f} s for {a.warmup} + {a.steps} passes at ~15 audio-s/s per GPU"
+              + (" - more than 400 s: consider fewer --steps" if est > 400 else ""), file=sys.stderr, flush=True)
 
     def one_pass():
         pred = sampler(model, x, a.ddim_steps, 0)
@@ -396,7 +425,12 @@ def main():
             "metric": "audio-seconds generated/sec, 2^16-sample stereo, 100-step v-DDIM",
             "value": total * Tn / SAMPLE_RATE / (ms * 1e-3), "unit": "audio-s/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling,
+            "scaling_note": ("N = 1 is BASELINE configs[1] (batch 16 on one GPU, the configuration the metric is quoted on); N > 1 is "
+                             "configs[4], a GLOBAL batch of 256 split N ways (strong scaling among N >= 2: 128 / 64 / 32 per GPU). "
+                             "The N = 1 point of that series is `--gpus 1 --batch 256`" if not a.batch else
+                             f"--batch {a.batch}: {a.batch} samples per GPU at every N (weak scaling)"),
+            "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": (f"configs[1]: DiffusionAttnUnet1D uncond (221M params, random init seed 0), batch {total} x 2ch x {T}"
                                     if world == 1 else
@@ -417,13 +451,13 @@ def main():
             if not a.no_roofline:
                 rec["roofline"] = conv_roofline(model, per_gpu, dtype, dev)
             if world == 1 and not a.no_extra:
-                rec["accuracy"] = first_call_accuracy(model, x, dtype, dev)
+                rec["accuracy"] = first_call_accuracy(model, x, dtype, dev, oracle_v0)
                 for k in [k for k in list(model._plans)]:             # free the timed dtype's arenas before the others
                     del model._plans[k]
                 torch.cuda.empty_cache()
                 for other in ("fp32", "bf16", "f16"):
                     if other != a.dtype and (other == "fp32" or a.dtype == "f16"):
-                        rec[other] = timed_pass(model, x, DT[other], a.ddim_steps, dev)
+                        rec[other] = timed_pass(model, x, DT[other], a.ddim_steps, dev, oracle_v0)
             errs = [p.plan.gn_error() if hasattr(p, "plan") else p.gn_error() for p in model._plans.values()]
             assert not any(errs), f"fused conv + GroupNorm kernels flagged an error: {errs}"
             rec["config"]["groupnorm"] = "fused into the producing conv's epilogue" if model.fuse_gn else "separate passes"

@@ -147,8 +147,13 @@ int adk_conv_postile(const adk_op *op);
 /* Output channels per block (32, 128 or 256) the conv kernel will use for this op. */
 int adk_conv_cotile_used(const adk_op *op);
 
-/* 1 if the conv op (dtype, B, L, Cout, CoutPad, taps, flags filled in) can run with ADK_FLAG_FUSE_GN: the pipelined
- * 128-channel tile (L > 128, Cout > 32), taps 3 / 5 / 7, at most 512 tiles per sample.  Host-only. */
+/* 1 if the conv op (dtype, B, L, Cout, CoutPad, taps, flags filled in) can run with ADK_FLAG_FUSE_GN on the CURRENT device:
+ * the pipelined 128-channel tile (L > 128, Cout > 32) or the short-level kernel, taps 3 / 5 / 7, at most 512 tiles per
+ * sample - and, for the pipelined kernel, a device that deals the workgroups of a grid evenly to 8 XCDs (its per-XCD ticket
+ * lists need that; a partitioned GPU does not).  The device is PROBED on the first call per device: two tiny launches and
+ * a synchronising 64-byte copy on the null stream (nothing is allocated), so make the first call outside stream capture -
+ * plan-building time.  A launch with ADK_FLAG_FUSE_GN on a device that was never probed probes it then (refused with
+ * ADK_EINVAL inside a capture). */
 int adk_conv_gn_fusable(const adk_op *op);
 
 /* Co-tile (rows of packed weight must be a multiple of this) the conv kernel will use. */

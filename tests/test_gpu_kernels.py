@@ -644,7 +644,7 @@ def test_pqmf_vs_golden(env, golden_pqmf, ch, att, M):
     assert rel_err(r, torch.from_numpy(z[f"{tag}/z"])) <= 1e-5
 
 
-@pytest.mark.parametrize("M", [4, 16])
+@pytest.mark.parametrize("M", [4, 16, 32])
 def test_pqmf_vs_reference_base_class(env, M):
     """the product's CachedPQMF (libadk kernels) against outputs of the reference's base-class PQMF
     (polyphase path, diffusion/pqmf.py:95-137, 212-233 - no cached_conv involved; tests/golden/glue.npz):

@@ -153,6 +153,17 @@ def test_full_model_first_call_and_10_steps():
     assert rel_err(v0h, ref_v0) <= 5e-3 and l2h <= 5e-3  # north_star: 1e-2; measured 1.9e-3
     predh = A.sample(m, x, 10, 0)
     assert torch.isfinite(predh).all() and snr_db(predh, ref) >= 60.0      # measured 79 dB: the fp32 bar, in half
+    # the DROP-IN DEFAULT: sample(model, x, steps, eta) with nothing configured runs the reference's autocast dtype
+    # (diffusion/sampling.py:30-31) and meets north_star's 1e-2 per denoiser call.  A 1-step loop returns
+    # pred = x * alpha_0 - v * sigma_0 with alpha_0 = cos(pi/2) ~ -4e-8, sigma_0 = 1: minus the first call's v.
+    m.compute_dtype = None
+    assert m.resolve_dtype(in_sampler=True) == torch.float16
+    v_default = -A.sample(m, x, 1, 0)
+    assert rel_err(v_default, ref_v0) <= 1e-2
+    pred_default = A.sample(m, x, 10, 0)
+    assert torch.equal(pred_default, predh) and snr_db(pred_default, ref) >= 60.0
+    with torch.autocast("cuda", dtype=torch.bfloat16):                      # an explicit autocast region still decides
+        assert m.resolve_dtype(in_sampler=True) == torch.bfloat16
     # bf16: bar derived from the operand-rounding floor of THIS model and input (CPU oracle, two calls)
     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
     fmax, fl2 = rounding_floor(sd, dict(n_attn_layers=4), x.cpu(), torch.ones(1), torch.bfloat16)
@@ -289,6 +300,42 @@ def test_cond_noise_aug_draws_noise():
     assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(c).all()
     d = m(x, t, cond=cond)                                 # Sobol-drawn level per sample (reference :155-156)
     assert torch.isfinite(d).all()
+
+
+def test_flagged_fused_launch_in_forward_falls_back_then_raises():
+    """The same rule for a direct model(x, t) call: forward() reads the error word after its plan has run, never returns
+    output computed past a flagged launch, falls back ONCE to the unfused plan with a warning, clears the (sticky) word
+    where it handles it, and raises when no fallback is left.  The error is injected by writing the word (the kernels
+    of a flagged plan stop waiting for statistics, so the flagged call's own output is garbage by construction)."""
+    import audio_diffusion_amd as A
+    from audio_diffusion_amd.unet import FusedLaunchError
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    m = A.DiffusionAttnUnet1D(depth=4, c_mults=[32, 64, 64, 128], n_attn_layers=1).to(dev).eval()
+    m.compute_dtype = torch.float32
+    torch.manual_seed(1)
+    x = torch.randn(2, 2, 4096, device=dev)
+    t = torch.tensor([0.3, 0.8], device=dev)
+    good = m(x, t)
+    plan = next(iter(m._plans.values()))
+    assert plan.fuse_gn and plan._gn_state is not None and plan.gn_error() == 0
+    off = plan._gn_state.off
+    plan.arena[off + 4:off + 8].view(torch.int32).fill_(0x60002001)
+    with pytest.warns(UserWarning, match="fuse_gn = False"):
+        again = m(x, t)
+    assert m.fuse_gn is False and rel_err(again, good) <= 1e-5
+    assert m.fused_error() == 0
+    # the word was cleared where it was handled: a fresh fused plan of the same model runs clean again
+    m.fuse_gn = True
+    m._plans = {}
+    assert torch.equal(m(x, t), good) and m.fused_error() == 0
+    # a plan whose model has fusion switched off meanwhile has nothing to fall back to: the flagged call raises
+    plan = next(iter(m._plans.values()))
+    plan.arena[plan._gn_state.off + 4:plan._gn_state.off + 8].view(torch.int32).fill_(0x71c0)
+    m.fuse_gn = False                                # (the cached plan is still the fused one)
+    with pytest.raises(FusedLaunchError):
+        m(x, t)
+    assert m.fused_error() == 0
 
 
 def test_flagged_fused_launch_falls_back_to_separate_groupnorm_passes():

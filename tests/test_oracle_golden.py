@@ -189,7 +189,7 @@ def test_crash_sampler_and_diffae_oracle_vs_reference_fixture():
     assert rel_err(got, torch.from_numpy(g["diffae/pred4"])) <= 1e-5
 
 
-@pytest.mark.parametrize("M", [4, 16])
+@pytest.mark.parametrize("M", [4, 16, 32])
 def test_base_pqmf_paths_and_cached_bank_cross_check(M):
     """pqmf.py:95-233 (PQMF, polyphase_* / classic_*): the oracle's restatements against the reference's outputs, and
     the cached bank the denoiser uses against them: CachedPQMF.forward == PQMF.forward exactly, CachedPQMF.inverse ==

@@ -430,7 +430,7 @@ def tier_glue(P, Model, ref):
         out["diffae/pred4"] = INF.sample(ToyDiffAE(), x, 4, 0)
     out["model_sd_check"] = m.state_dict()["net.0.main.0.weight"][:2, :2]
 
-    for M in (4, 16):
+    for M in (4, 16, 32):                  # 32 = config 4's bank
         torch.manual_seed(7)
         xb = torch.randn(2, 1, M * 96)
         for poly in (True, False):

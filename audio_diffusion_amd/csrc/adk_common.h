@@ -59,9 +59,16 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     // issue-timing dependent hazard this instruction mix avoids.  pack2v below is the one-instruction form, used by
     // the GroupNorm pass only (its statistics are taken before the conversion in separate registers; verified
     // bit-reproducible with the same tool).
+#ifdef ADK_EXP_PACK1      /* experiment / lint build only: the one-instruction form round 1 reverted (tools/isa_lint.py was run on it) */
+    f32x2 v2; v2.x = lo; v2.y = hi;
+    union { bf16x2 h; uint32_t u; } cv1;
+    cv1.h = __builtin_convertvector(v2, bf16x2);
+    return cv1.u;
+#else
     union { bf16_t h[2]; uint32_t u; } cv;
     cv.h[0] = (bf16_t)lo; cv.h[1] = (bf16_t)hi;
     return cv.u;
+#endif
 }
 // two 16-bit elements of one 32-bit word <-> two floats (element 0 in the low half)
 __device__ __forceinline__ f32x2 unpack2(uint32_t w, bf16_t) {

@@ -57,9 +57,24 @@ template <int OFF, typename Frag> __device__ __forceinline__ void lds_read128(Fr
     static_assert(sizeof(Frag) == 16 && OFF >= 0 && OFF < 65536, "one ds_read_b128, immediate offset");
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
 }
+// tools/isa_lint.py checks this pattern in the machine code that ships (no instruction may name a fragment register
+// between its ds_read_b128 and the counted wait that covers it; MFMA wait states; no stray vector-memory instruction in
+// the counted-vmcnt loop).  Its positive controls are two deliberately broken builds of this file, never shipped:
+//   -DADK_LINT_CONTROL_WEAK_WAIT  every counted fragment wait one too weak (rule a must fire);
+//   -DADK_LINT_CONTROL_ACC_TIE    the wrong turn described below, re-created (rule b must fire).
+#ifdef ADK_LINT_CONTROL_WEAK_WAIT
+#define ADK_LDS_WAIT_SLACK 1
+#else
+#define ADK_LDS_WAIT_SLACK 0
+#endif
 template <int N, typename Frag> __device__ __forceinline__ void lds_wait(Frag& f) {
-    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N + ADK_LDS_WAIT_SLACK) : "memory");
 }
+#ifdef ADK_LINT_CONTROL_ACC_TIE
+template <int N, typename Frag> __device__ __forceinline__ void lds_wait_tie(Frag& f, f32x16& c0, f32x16& c1) {
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(f), "+v"(c0), "+v"(c1) : "n"(N) : "memory");
+}
+#endif
 // (NEVER pass an accumulator through such an asm to order it after the MFMAs that write it: a version of this loop tied
 // each wait to the previous step's accumulator tuple as an in/out operand.  The compiler then takes the asm - not the
 // MFMA still in flight - for the producer of those registers, its hazard recogniser stops inserting the wait states an
@@ -239,8 +254,13 @@ __device__ __forceinline__ ConvTileId conv_tile_mainloop16(const ConvArgs& a, co
         // step y: wait for B[y] (requested three steps ago; at y = 0 also this unit's A fragments), request B[y+3] (of the
         // next unit from y = 5) and, in the first four steps, the next unit's A[y]; then the four MFMAs A[0..3] x B[y].
         // Reads per step: 2, 2, 2, 2, 1, 1, 1, 1 -> reads younger than B[y] when step y starts: 2, 3, 4, 4, 4, 3, 2, 2.
+#ifdef ADK_LINT_CONTROL_ACC_TIE
+#define ADK_STEP_WAIT(Y_, NYOUNGER_) lds_wait_tie<NYOUNGER_>(bq[(Y_) & 3], acc[0][((Y_) - 1) >> 1], acc[1][((Y_) - 1) >> 1]);
+#else
+#define ADK_STEP_WAIT(Y_, NYOUNGER_) lds_wait<NYOUNGER_>(bq[(Y_) & 3]);
+#endif
 #define ADK_STEP(Y_, NYOUNGER_)                                                                              \
-        if constexpr ((Y_) == 0) lds_wait<NYOUNGER_>(bq[0], aq[PAR_]); else lds_wait<NYOUNGER_>(bq[(Y_) & 3]);   \
+        if constexpr ((Y_) == 0) lds_wait<NYOUNGER_>(bq[0], aq[PAR_]); else ADK_STEP_WAIT(Y_, NYOUNGER_)        \
         if constexpr ((Y_) + 3 < NB) lds_read128<((Y_) + 3) * 1024>(bq[((Y_) + 3) & 3], xt_c);               \
         else lds_read128<((Y_) + 3 - NB) * 1024>(bq[((Y_) + 3) & 3], xt_n);                                  \
         if constexpr ((Y_) < NA) lds_read128<((Y_) & 3) * 1024>(aq[PAR_ ^ 1][(Y_) & 3], wt_n);               \
@@ -250,6 +270,7 @@ __device__ __forceinline__ ConvTileId conv_tile_mainloop16(const ConvArgs& a, co
         mma16_sub<2 + ((Y_) & 1)>(aq[PAR_][3], bq[(Y_) & 3], acc[1][(Y_) >> 1]);
         ADK_STEP(0, 2) ADK_STEP(1, 3) ADK_STEP(2, 4) ADK_STEP(3, 4) ADK_STEP(4, 4) ADK_STEP(5, 3) ADK_STEP(6, 2) ADK_STEP(7, 2)
 #undef ADK_STEP
+#undef ADK_STEP_WAIT
     };
     auto chunk = [&](auto parc, const int kc) {
         constexpr int P0 = decltype(parc)::value;

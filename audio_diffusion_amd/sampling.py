@@ -56,6 +56,7 @@ def step_coefficients(steps, eta, warp=None):
 
 class _FusedSampler:
     """Captured step loop for one (model, B, T, dtype, steps)."""
+    replay_window = 16          # steps the host may run ahead of the GPU (0 = unbounded)
 
     def __init__(self, model, x, steps, dtype, use_graph=True, cond_shape=None):
         dev = x.device
@@ -106,12 +107,26 @@ class _FusedSampler:
                 self._one_step(torch.cuda.current_stream(x.device).cuda_stream)
             self.graph = g
             # capture does not execute: state is still at step 0
-        sp = torch.cuda.current_stream(x.device).cuda_stream
+        stream = torch.cuda.current_stream(x.device)
+        sp = stream.cuda_stream
+        # The host enqueues a replay in microseconds and a step takes 15-90 ms, so without a bound all `steps` launches
+        # (100 x ~300 kernel nodes) sit in the queue at once.  That is legal, and it is also what made the process die
+        # with SIGSEGV inside rocprofv3's interception frames (fp32, 100 steps; DESIGN.md section 8: not with 20 steps,
+        # not in an eager loop, not when the run-ahead is bounded).  Keep at most `replay_window` steps in flight: the
+        # host waits for the event of step i - window before it enqueues step i, so the queue never runs dry either.
+        window = int(self.replay_window or 0)
+        events = []
         for i in range(self.steps):
+            if window and i >= window:
+                events[i - window].synchronize()
             if self.graph is not None:
                 self.graph.replay()
             else:
                 self._one_step(sp)
+            if window and i + window < self.steps:
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                events.append(ev)
             if i == 0:
                 # The fused conv + GroupNorm launches wait, bounded, for the other tiles of a sample; a wait that ran out
                 # (or tickets out of step) leaves an error word instead of a hang.  A GPU that cannot run them (shared
@@ -121,6 +136,13 @@ class _FusedSampler:
         out = self.pred.clone()
         self._check()                 # ... and never hand back audio computed past a flagged launch
         return out
+
+    def close(self):
+        """Destroy the captured graph while everything its nodes point at (arena, coefficient table, step counter, x / v /
+        pred) is still allocated."""
+        if self.graph is not None:
+            self.graph.reset()
+            self.graph = None
 
     def _check(self):
         err = self.plan.gn_error(clear=True)          # the host clears the sticky word where it raises

@@ -674,8 +674,24 @@ class DiffusionAttnUnet1D(nn.Module):
     # ---- cache management ----------------------------------------------------------------
     def invalidate_cache(self):
         """Drop packed weights and compiled plans (call after mutating parameters in place)."""
+        self.release_plans()
         self._wcache = {}
-        self._plans = {}
+
+    def release_plans(self, dtype=None):
+        """Drop the compiled plans and captured samplers (of one compute dtype, or all) in an ORDERLY way: the device is
+        idle first, every captured hipGraph is destroyed BEFORE the arena and the coefficient / step buffers whose
+        addresses its kernel nodes hold, and only then do the tensors go back to the allocator."""
+        keys = [k for k in self._plans if dtype is None or dtype in k]
+        if not keys:
+            return
+        if torch.cuda.is_available() and any(getattr(self._plans[k], "graph", None) is not None for k in keys):
+            torch.cuda.synchronize()
+        for k in keys:
+            close = getattr(self._plans[k], "close", None)
+            if close is not None:
+                close()
+        for k in keys:
+            del self._plans[k]
 
     def load_state_dict(self, *a, **k):
         out = super().load_state_dict(*a, **k)

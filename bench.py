@@ -267,6 +267,23 @@ def first_call_accuracy(model, x, dtype, dev, oracle_v0=None):
     return rec
 
 
+TEARDOWN = "ordered"       # --teardown: ordered | drop (round 2's form: del + empty_cache) | keep (hold everything)
+
+
+def release(model, dtype, dev):
+    """Give one dtype's plans (captured graph + arena) back before the next dtype's are built."""
+    import torch
+    if TEARDOWN == "keep":
+        return
+    if TEARDOWN == "drop":
+        for k in [k for k in model._plans if dtype is None or dtype in k]:
+            del model._plans[k]
+    else:
+        model.release_plans(dtype)
+        torch.cuda.synchronize(dev)
+    torch.cuda.empty_cache()
+
+
 def timed_pass(model, x, dtype, ddim_steps, dev, oracle_v0=None):
     """ONE timed pass of the workload in another dtype (plan build, graph capture and one untimed pass first)."""
     import torch
@@ -284,9 +301,7 @@ def timed_pass(model, x, dtype, ddim_steps, dev, oracle_v0=None):
         acc = first_call_accuracy(model, x, dtype, dev, oracle_v0)
     finally:
         model.compute_dtype = prev
-        for k in [k for k in model._plans if dtype in k]:         # release this dtype's arena
-            del model._plans[k]
-        torch.cuda.empty_cache()
+        release(model, dtype, dev)                                # this dtype's arena
     B = x.shape[0]
     rec = {"value": B * T / SAMPLE_RATE / dt, "unit": "audio-s/s", "passes": 1, "ms_per_step": dt * 1e3,
            "ms_per_denoiser_call": dt * 1e3 / ddim_steps,
@@ -294,6 +309,12 @@ def timed_pass(model, x, dtype, ddim_steps, dev, oracle_v0=None):
     if acc:
         rec["accuracy"] = acc
     return rec
+
+
+def phase(msg):
+    """Progress marker on stderr (ADK_BENCH_PHASES=1): where a run under a profiler was when it died."""
+    if os.environ.get("ADK_BENCH_PHASES"):
+        print(f"[bench {time.perf_counter():.2f}] {msg}", file=sys.stderr, flush=True)
 
 
 def free_port():
@@ -333,7 +354,11 @@ def main():
     ap.add_argument("--standin", action="store_true",
                     help="CPU rehearsal: a stand-in per-sample function replaces the HIP sampler (launcher, sharding, "
                          "all-gather and the JSON line are the real ones); never a measurement")
+    ap.add_argument("--teardown", default="ordered", choices=["ordered", "drop", "keep"],
+                    help="how the plans of one dtype are released before the next dtype's pass (diagnostic for the rocprofv3 crash)")
     a = ap.parse_args()
+    global TEARDOWN
+    TEARDOWN = a.teardown
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(a, sys.argv[1:]))
@@ -404,16 +429,19 @@ def main():
         if not a.standin:
             torch.cuda.synchronize(dev)
 
+    phase("model on device; warm-up passes")
     for _ in range(a.warmup):
         one_pass()
     D.barrier(world)
     sync()
+    phase("timed passes")
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = one_pass()
     D.barrier(world)
     sync()
     dt = time.perf_counter() - t0
+    phase("timed passes done")
     dt = D.max_over_ranks(dt, world, dev)
     assert out.shape[0] == total and torch.isfinite(out).all()
 
@@ -449,14 +477,16 @@ def main():
             rec["data"] = "STAND-IN sampler on CPU (launcher rehearsal, not a measurement)"
         else:
             if not a.no_roofline:
+                phase("roofline: per-launch event timing")
                 rec["roofline"] = conv_roofline(model, per_gpu, dtype, dev)
             if world == 1 and not a.no_extra:
+                phase("accuracy: fp32 + timed dtype, one call each")
                 rec["accuracy"] = first_call_accuracy(model, x, dtype, dev, oracle_v0)
-                for k in [k for k in list(model._plans)]:             # free the timed dtype's arenas before the others
-                    del model._plans[k]
-                torch.cuda.empty_cache()
+                phase("release plans")
+                release(model, None, dev)                             # free the timed dtype's arenas before the others
                 for other in ("fp32", "bf16", "f16"):
                     if other != a.dtype and (other == "fp32" or a.dtype == "f16"):
+                        phase(f"one timed pass in {other}")
                         rec[other] = timed_pass(model, x, DT[other], a.ddim_steps, dev, oracle_v0)
             errs = [p.plan.gn_error() if hasattr(p, "plan") else p.gn_error() for p in model._plans.values()]
             assert not any(errs), f"fused conv + GroupNorm kernels flagged an error: {errs}"

@@ -18,7 +18,7 @@ struct ConvArgs {
     unsigned* gn_err;            // set to a non-zero code when a bounded wait runs out
     unsigned* gn_ticket;         // this op's tile counter (grows by nblk per forward)
     unsigned gn_slot, gn_cap;             // gn_cap: resident block slots of the kernel on this device
-    unsigned gn_grid;                     // blocks launched when tiles go by ticket: nblk + gn_spare(nblk)
+    unsigned gn_grid;                     // blocks launched when tiles go by ticket: 8 x the longest per-XCD list
     int npb, gelu;               // tiles per sample (= tps * ncot)
     float eps; double gn_count;  // Cout * L
     // ADK_FLAG_PRE_NORM: GroupNorm(1, Cin) of the INPUT folded into the conv (attention's norm -> qkv_proj): the weights carry
@@ -99,15 +99,6 @@ __device__ __forceinline__ void raw_to_float4(const uint2& t, float (&v)[4], f16
     const f32x2 a = unpack2(t.x, f16_t()), b = unpack2(t.y, f16_t());
     v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
 }
-
-// Spare blocks of a ticketed launch.  Workgroups are bound to XCDs round-robin at launch and every XCD works through its
-// own queue, so the queues run dry at different times.  With exactly one block per tile, the last unstarted tiles of the
-// last sample can sit in the queue of a lagging XCD behind 64 slots full of blocks that wait for exactly those tiles
-// (seen about once per 10^4 launches at B = 128: the bounded wait expired on the LAST sample).  With spare blocks the
-// XCDs that are ahead keep starting blocks - which take the next tickets, whatever queue they came from - until the
-// tickets are gone; the blocks left over (mostly the lagging XCD's) find no ticket and exit.  An eighth of the grid
-// (at least 64) covers one XCD being 12.5 % ahead of the mean; the cost is one atomic per spare block at the tail.
-__host__ __device__ inline unsigned gn_spare(unsigned nblk) { const unsigned e = (nblk / 8 + 7) & ~7u; return e < 64u ? 64u : e; }
 
 // tile shape chosen on the host for one conv op (conv_mfma.hip: conv_tile)
 struct ConvTile { int bn, bm; bool ksplit; };

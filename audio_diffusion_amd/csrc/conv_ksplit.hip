@@ -40,17 +40,26 @@ __global__ __launch_bounds__(256, (TCO * TPOS >= 4 ? 1 : 2)) void conv_ksplit_ke
     if constexpr (GN) {
         const unsigned ebase = a.gn_epoch[0];
         epoch = ebase * 4096u + a.gn_slot + 1u;
-        if (a.nblk > a.gn_cap) {                             // not all blocks resident at once: tiles by ticket, sample-major
+        if (a.nblk > a.gn_cap) {
+            // Not all blocks resident at once: tiles go by ticket, sample-major, ONE LIST PER XCD exactly as in the pipelined
+            // kernel (conv_mfma_gn.inc has the argument): tile q of the sample-major order belongs to list q % 8, a block takes
+            // the next tile of the list of the XCD it runs on, the grid is 8 x the longest list.  XCD k then only ever holds
+            // list-k tiles in sample-major start order, at most ceil(npb / 8) - 1 of them wait for a sample's missing tile,
+            // and that tile is the next workgroup in XCD k's own queue: no spare blocks, nothing statistical.
             unsigned* tick = reinterpret_cast<unsigned*>(smem);
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            const unsigned xk = xcc & 7u;
             if (threadIdx.x == 0) {
-                const unsigned old = __hip_atomic_fetch_add((gu32*)(a.gn_ticket), 1u, ADK_RLX_AGENT);
-                *tick = old - (ebase - 1u) * a.gn_grid;
+                const unsigned old = __hip_atomic_fetch_add((gu32*)(a.gn_ticket) + xk * GN_LIST_STRIDE, 1u, ADK_RLX_AGENT);
+                *tick = old - (ebase - 1u) * (a.gn_grid >> 3);     // this list's counter grows by grid / 8 per forward
             }
             __syncthreads();
-            lid = __builtin_amdgcn_readfirstlane(*tick);
+            const unsigned n = __builtin_amdgcn_readfirstlane(*tick);
             __syncthreads();
-            if (lid >= a.nblk) {                             // a spare block (gn_spare), or - beyond the grid - counter out of step
-                if (lid >= a.gn_grid && threadIdx.x == 0) __hip_atomic_store((gu32*)(a.gn_err), 0x71c1u, ADK_RLX_AGENT);
+            lid = xk + 8u * n;
+            if (lid >= a.nblk) {                             // beyond the end of its list; beyond the grid's share: counter out of step
+                if (n >= (a.gn_grid >> 3) && threadIdx.x == 0) __hip_atomic_store((gu32*)(a.gn_err), 0x71c1u, ADK_RLX_AGENT);
                 return;
             }
             b = (int)(lid / (unsigned)a.npb);
@@ -377,9 +386,17 @@ static int launch_ks(const adk_op& op, hipStream_t st)
             }
             if (a.npb > capd) return ADK_EINVAL;
             a.gn_cap = (unsigned)capd;
-            // ticketed (more blocks than resident slots): spare blocks, see gn_spare; else every block is resident
-            hipLaunchKernelGGL((conv_ksplit_kernel<T, TO, TAPS, TCO, TPOS, DEPTH, true>),
-                               dim3(a.nblk > a.gn_cap ? a.gn_grid : a.nblk), dim3(256), lds, st, a);
+            // ticketed (more blocks than resident slots): one list per XCD, grid = 8 x the longest list, a sample's share of a
+            // list must fit the XCD's slots, and the device must deal workgroups evenly to 8 XCDs; else every block is resident
+            unsigned grid = a.nblk;
+            if (a.nblk > a.gn_cap) {
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+                if (!gn_device_ok(nullptr, !capturing)) return ADK_EINVAL;
+                if (((unsigned)a.npb + 7u) / 8u > a.gn_cap / 8u) return ADK_EINVAL;
+                a.gn_grid = grid = 8u * ((a.nblk + 7u) / 8u);
+            }
+            hipLaunchKernelGGL((conv_ksplit_kernel<T, TO, TAPS, TCO, TPOS, DEPTH, true>), dim3(grid), dim3(256), lds, st, a);
             return hipGetLastError() == hipSuccess ? ADK_OK : ADK_ELAUNCH;
         }
     }

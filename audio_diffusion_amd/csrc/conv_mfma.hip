@@ -33,7 +33,7 @@ void conv_fill_args(const adk_op& op, int BN, int BM, ConvArgs& a)
     a.shift = (op.flags & ADK_FLAG_CAUSAL) ? (op.taps - 1) * a.dil : (op.taps / 2) * a.dil;
     a.elu = (op.flags & ADK_FLAG_ELU) ? 1 : 0;
     a.gamma = a.beta = nullptr; a.gn_ws = nullptr; a.gn_epoch = nullptr; a.gn_err = nullptr;
-    a.gn_slot = a.gn_cap = 0; a.gn_grid = a.nblk + gn_spare(a.nblk); a.gn_ticket = nullptr; a.npb = a.tps * a.ncot; a.gelu = 0; a.eps = 0.f; a.gn_count = 1.0;
+    a.gn_slot = a.gn_cap = 0; a.gn_grid = a.nblk; a.gn_ticket = nullptr; a.npb = a.tps * a.ncot; a.gelu = 0; a.eps = 0.f; a.gn_count = 1.0;
     if (op.flags & ADK_FLAG_FUSE_GN) {
         a.gamma = op.gamma; a.beta = op.beta;
         a.gn_ws = reinterpret_cast<unsigned long long*>(op.aux1);

@@ -2,7 +2,7 @@
 """Denoiser-call timings for the BASELINE.json configs that are not bench.py's headline line:
 config 2 in fp32, config 3a / 3b (long context), config 4 (PQMF-banded) and the PQMF kernels alone.
 
-usage: python tools/bench_configs.py [--reps 5] [--only 3a,4]
+usage: python tools/bench_configs.py [--reps 5] [--only 3a,4] [--dtype f16|bf16]
 Prints one JSON line per config (ms per denoiser call, algorithmic TFLOP/s, audio-s/s at 100 DDIM steps).
 Synthetic inputs, random-init weights (seed 0)."""
 import argparse
@@ -56,11 +56,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="")
+    ap.add_argument("--dtype", default="", help="f16 | bf16: run every 16-bit config in this dtype (default: as listed, bf16)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     names = [n for n in CONFIGS if not a.only or n in a.only.split(",")]
     for name in names:
         kw, B, T, dtype = CONFIGS[name]
+        if a.dtype and dtype != torch.float32:
+            dtype = {"f16": torch.float16, "bf16": torch.bfloat16}[a.dtype]
         torch.manual_seed(0)
         if name == "soundstream-dec":
             from audio_diffusion_amd.soundstream import SoundStreamXLDecoder

@@ -202,3 +202,38 @@ def test_config5_two_gpu_shard_of_128_soak():
     plan = [p for p in m._plans.values() if hasattr(p, "plan")][0].plan
     assert plan.gn_error() == 0
     assert torch.equal(A.sample(m, x[77:78].contiguous(), 25, 0)[0], pred[77]), "a sample's result must not depend on its shard"
+
+
+def test_config5_rccl_backend_single_rank():
+    """configs[4]'s collective path through the REAL backend: `distributed.init(backend="nccl")` (= RCCL on ROCm), the
+    all-gather of the output audio, the max-over-ranks all-reduce and the barrier that bench.py uses at N > 1 - with the one
+    rank a one-GPU box allows (RCCL refuses two ranks on one device).  A single-rank communicator moves no bytes over
+    xGMI; what this covers is that the library loads, the communicator initialises on this image, and every collective
+    call of distributed.py runs on device tensors and returns the 1-rank result bit for bit."""
+    import socket
+    import os
+    import audio_diffusion_amd as A
+    from audio_diffusion_amd import distributed as D
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("a process group is already initialised in this process")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(s.getsockname()[1])
+    s.close()
+    kw = dict(depth=4, c_mults=[32, 64, 64, 128], n_attn_layers=1)
+    m, _ = make(**kw)
+    g = torch.Generator().manual_seed(1)
+    noise = torch.randn(4, 2, 4096, generator=g).to(DEV)
+    want = A.sample(m, noise, 4, 0)
+    D.init(0, 1, backend="nccl")
+    try:
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        got = D.sample_sharded(m, noise, 4, 0, sampler=A.sample)
+        assert got.is_cuda and torch.equal(got, want)
+        assert torch.equal(D.all_gather_audio(want[:3].contiguous()), want[:3])
+        assert D.max_over_ranks(3.5, 2, torch.device(DEV)) == 3.5        # world > 1 forces the all-reduce call
+        dist.barrier()
+        torch.cuda.synchronize()
+    finally:
+        D.shutdown()

@@ -117,10 +117,38 @@ __device__ __forceinline__ uint4 float_to_piece(const float (&f)[8], bf16_t) {
 }
 
 // ---- deterministic reductions ----------------------------------------------------------------
+// Cross-lane moves by DPP (data-parallel primitives: the VALU reads its operand from another lane of the same 16-lane row,
+// no LDS round trip).  __shfl_xor compiles to ds_bpermute_b32 + an lgkmcnt(0) wait per step: about 700 cycles for a
+// 64-lane sum, on the critical path between a tile's last MFMA and the statistics it publishes; the DPP form is ~60.
+// Every caller runs with all 64 lanes active (wave-uniform control flow), which DPP needs.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ float lane_value(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ double lane_value(double v, int lane) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140,
+              DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128;
+
+// Sum over the 64 lanes, the same value on every lane; a fixed tree (within quads, half rows, rows, then the four rows in
+// the order (0 + 1) + (2 + 3)): bit-reproducible.
 template <typename V> __device__ __forceinline__ V wave_sum(V v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov<DPP_QUAD_XOR1>(v);
+    v += dpp_mov<DPP_QUAD_XOR2>(v);
+    v += dpp_mov<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_mov<DPP_ROW_MIRROR>(v);
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 
 // Block-wide sum of two values with 256 threads; every thread gets the result. `red` = 16 V's of LDS.
@@ -164,6 +192,12 @@ __device__ __forceinline__ void gn_finalize_wave(const float* __restrict__ parti
     mean = (float)mu;
     rstd = (float)(1.0 / sqrt(var + (double)eps));
 }
+
+// a * b + c with ONE rounding, written out: the GroupNorm affine must give the same bits in every instantiation that
+// applies it (with / without output statistics, the branch-free epilogue and the masked one, in place or not).  Left as
+// `a * b + c` the contraction is the compiler's choice per instantiation - round 3 saw the SLP vectoriser turn it into
+// v_pk_mul + v_pk_add in one gn_kernel variant and v_pk_fma in its sibling (1 ulp apart, caught by the in-place test).
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 // exact GELU (nn.GELU default, approximate='none'): 0.5*x*(1+erf(x/sqrt(2)))
 __device__ __forceinline__ float gelu_erf(float x) {

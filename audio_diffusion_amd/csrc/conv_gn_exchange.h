@@ -66,9 +66,14 @@ __device__ __forceinline__ void gn_gather(const ConvArgs& a, int b, unsigned epo
     double acc_d = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc_d += (double)__uint_as_float((unsigned)x[k]);
-#pragma unroll
-    for (int o = 32; o >= 2; o >>= 1) acc_d += __shfl_xor(acc_d, o, 64);        // within each parity class
-    const double q = __shfl(acc_d, 1, 64), tot = __shfl(acc_d, 0, 64);
+    // within each parity class (even lanes: sums, odd lanes: sums of squares), by DPP moves that keep a lane's parity:
+    // xor 2 inside a quad, then rotations by 4 and 8 inside the 16-lane row; lanes 0 / 1 of the four rows then hold the
+    // row totals of the two classes, added in the order (0 + 1) + (2 + 3).  A fixed tree, as the shuffle butterfly was.
+    acc_d += dpp_mov<DPP_QUAD_XOR2>(acc_d);
+    acc_d += dpp_mov<DPP_ROW_ROR4>(acc_d);
+    acc_d += dpp_mov<DPP_ROW_ROR8>(acc_d);
+    const double tot = (lane_value(acc_d, 0) + lane_value(acc_d, 16)) + (lane_value(acc_d, 32) + lane_value(acc_d, 48));
+    const double q = (lane_value(acc_d, 1) + lane_value(acc_d, 17)) + (lane_value(acc_d, 33) + lane_value(acc_d, 49));
     const double mu = tot / a.gn_count;
     double var = q / a.gn_count - mu * mu;
     if (var < 0.0) var = 0.0;

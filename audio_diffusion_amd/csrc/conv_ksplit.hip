@@ -243,8 +243,8 @@ __global__ __launch_bounds__(256, (TCO * TPOS >= 4 ? 1 : 2)) void conv_ksplit_ke
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float sc = g4[e] * rstd, sh = b4[e] - mean * sc;
-                        v[e] = vv[i][j][e] * sc + sh;
+                        const float sc = g4[e] * rstd, sh = __builtin_fmaf(-mean, sc, b4[e]);
+                        v[e] = __builtin_fmaf(vv[i][j][e], sc, sh);
                         if (a.gelu) v[e] = gelu_for<T>(v[e]);
                     }
                     if (rg) {

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void gn_kernel(const GnArgs a)
         for (int e = 0; e < NV; ++e) {
             const bool real = c0 + e < a.C;          // pad channels stay exactly zero
             scale[e] = real ? (gm[c0 + e] + a.ada) * rstd : 0.f;
-            shift[e] = real ? bt[c0 + e] - mean * scale[e] : 0.f;
+            shift[e] = real ? __builtin_fmaf(-mean, scale[e], bt[c0 + e]) : 0.f;
         }
     }
     float s1 = 0.f, s2 = 0.f;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void gn_kernel(const GnArgs a)
                 if (APPLY) {
                     f32x2 sc, sh;
                     sc.x = scale[2 * i]; sc.y = scale[2 * i + 1]; sh.x = shift[2 * i]; sh.y = shift[2 * i + 1];
-                    v = v * sc + sh;
+                    v = fma2(v, sc, sh);
                     if (GELU) v = gelu_fast2(v);
                     if (RES) {
                         v += unpack2(rw[i], T());
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void gn_kernel(const GnArgs a)
             if (APPLY) {
 #pragma unroll
                 for (int e = 0; e < NV; ++e) {
-                    float v = f[e] * scale[e] + shift[e];
+                    float v = __builtin_fmaf(f[e], scale[e], shift[e]);
                     f[e] = GELU ? gelu_for<T>(v) : v;
                 }
                 if (RES) {

@@ -9,6 +9,10 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
 #define ADK_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
+#ifndef ADK_GN_POLL_SLEEP      /* s_sleep argument between two polls (x 64 cycles). Same-box, whole sampler:
+                                * 2 / 8 / 32 within 0.2 % of each other, 100 is 2 % slower (profiles/r03/v3_ab_poll_sleep.txt) */
+#define ADK_GN_POLL_SLEEP 8
+#endif
 constexpr unsigned GN_SPIN_LIMIT = 1u << 20;     // ~1 us per poll: gives up after about a second
 constexpr unsigned GN_LIST_STRIDE = 512;         // words between the ticket counters of two XCDs' lists (separate L2 lines):
                                                  // counter of (slot, XCD k) = counters[k * 512 + slot], slot < 511
@@ -61,7 +65,7 @@ __device__ __forceinline__ void gn_gather(const ConvArgs& a, int b, unsigned epo
                 if (!(have & (1u << k))) x[k] = 0;
             break;
         }
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(ADK_GN_POLL_SLEEP);
     }
     double acc_d = 0.0;
 #pragma unroll

@@ -155,6 +155,45 @@ struct AttnMfmaArgs {
 
 constexpr int ATT_VBUF = 2048;              // one 32-key V tile, linear [key][32] bf16
 
+// Keys past the end of the sample get a score of -inf.  Only the LAST 32-key tile of a sample can be partial and `ragged`
+// is wave-uniform; register r of a lane holds key 32 kt + (r & 3) + 8 (r >> 2) + 4 h, `lim` = last - 32 kt - 4 h.  The
+// limit passes through an opaque asm INSIDE the branch: otherwise the compiler hoists the 16 compares in front of the
+// branch and every tile pays for them (16 of the ~76 VALU instructions per 32 x 32 score tile; round 3, tools/loop_mix.py).
+__device__ __forceinline__ void att_mask_tail(f32x16& s, const bool ragged, const int lim)
+{
+    if (ragged) {
+        int l = lim;
+#ifndef ADK_EXP_ATT_OLD           // experiment builds: the previous instruction mix, for the A/B
+        asm volatile("; partial key tile" : "+v"(l));
+#endif
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if ((r & 3) + 8 * (r >> 2) > l) s[r] = -INFINITY;
+    }
+}
+
+// max / sum of a value with the one 32 lanes away (the two key halves of a query column).  One v_permlane32_swap of the
+// value with itself gives [lo, lo] and [hi, hi]; __shfl_xor(x, 32) was a ds_bpermute: five address instructions, an LDS
+// round trip and an lgkmcnt(0) that also waited for the tile's fragment reads.  Same bits (max is exact, + commutes).
+__device__ __forceinline__ float att_xhalf_max(const float x)
+{
+#ifdef ADK_EXP_ATT_OLD
+    return fmaxf(x, __shfl_xor(x, 32, 64));
+#else
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+#endif
+}
+__device__ __forceinline__ float att_xhalf_sum(const float x)
+{
+#ifdef ADK_EXP_ATT_OLD
+    return x + __shfl_xor(x, 32, 64);
+#else
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+#endif
+}
+
 template <typename T> struct AttMma;           // 16-bit element type -> fragment type + MFMA (same shapes, same rate)
 template <> struct AttMma<bf16_t> {
     typedef bf16x8 Frag;
@@ -277,15 +316,11 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnMfmaArgs a)
                 st = AttMma<T>::run(kf[p][1].f, qf[u][p][1], st);
             }
             // st[r] = <k_key, q_query>, key = 32 kt + (r & 3) + 8 (r >> 2) + 4 h, query = l31
-            if (ragged) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h > last) st[r] = -INFINITY;
-            }
+            att_mask_tail(st, ragged, last - kt * 32 - 4 * h);
             float mx = st[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = att_xhalf_max(mx);
             const float mnew = fmaxf(mrun[u], mx * c);
             const float alpha = __builtin_amdgcn_exp2f(mrun[u] - mnew);
             const bool rescale = __ballot(mnew != mrun[u]) != 0ull;   // alpha == 1 exactly on every lane otherwise
@@ -332,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(const AttnMfmaArgs a)
     unsigned char* yb = reinterpret_cast<unsigned char*>(a.y) + ((long long)hd * DP * a.M + srow) * 64;
 #pragma unroll
     for (int u = 0; u < TQ; ++u) {
-        const float ltot = lrun[u] + __shfl_xor(lrun[u], 32, 64);
+        const float ltot = att_xhalf_sum(lrun[u]);
         const float inv = 1.0f / ltot;
         const int q = (qt * TQ + u) * 32 + l31;
         if (q <= last) {
@@ -468,15 +503,11 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_f32_kernel(const AttnMfmaArg
                     st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t][e].z, qf[u][t][e].z, st, 0, 0, 0);
                     st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t][e].w, qf[u][t][e].w, st, 0, 0, 0);
                 }
-            if (ragged) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h > last) st[r] = -INFINITY;
-            }
+            att_mask_tail(st, ragged, last - kt * 32 - 4 * h);
             float mx = st[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = att_xhalf_max(mx);
             const float mnew = fmaxf(mrun[u], mx * c);
             const float alpha = __builtin_amdgcn_exp2f(mrun[u] - mnew);
             mrun[u] = mnew;
@@ -504,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_f32_kernel(const AttnMfmaArg
     unsigned char* yb = reinterpret_cast<unsigned char*>(a.y) + ((long long)hd * PPH * a.M + srow) * 64;
 #pragma unroll
     for (int u = 0; u < TQ; ++u) {
-        const float ltot = lrun[u] + __shfl_xor(lrun[u], 32, 64);
+        const float ltot = att_xhalf_sum(lrun[u]);
         const float inv = 1.0f / ltot;
         const int q = (qt * TQ + u) * 32 + l31;
         if (q <= last) {
@@ -720,15 +751,11 @@ __global__ __launch_bounds__(256) void attn_qkv_kernel(const AttnQkvArgs a)
             for (int r = 0; r < 16; ++r) st[r] = 0.f;
             st = AttMma<T>::run(kf[0], qf[0], st);
             st = AttMma<T>::run(kf[1], qf[1], st);
-            if ((kt + 1) * 32 > a.L) {                      // wave-uniform: only the last tile can be partial
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h > last) st[r] = -INFINITY;
-            }
+            att_mask_tail(st, (kt + 1) * 32 > a.L, last - kt * 32 - 4 * h);
             float mx = st[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = att_xhalf_max(mx);
             const float mnew = fmaxf(mrun, mx * c);
             const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
             mrun = mnew;
@@ -756,7 +783,7 @@ __global__ __launch_bounds__(256) void attn_qkv_kernel(const AttnQkvArgs a)
             o = AttMma<T>::run(vf[0], pf[0], o);
             o = AttMma<T>::run(vf[1], pf[1], o);
         }
-        const float ltot = lrun + __shfl_xor(lrun, 32, 64);
+        const float ltot = att_xhalf_sum(lrun);
         const float inv = 1.0f / ltot;
         const int q = qt * 32 + l31;
         if (q <= last) {
@@ -922,15 +949,11 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_lds_kernel(const AttnMfmaArg
             bool rescale[TQ];
 #pragma unroll
             for (int u = u0; u < u0 + UG; ++u) {
-                if (ragged) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h > last) sc[u][r] = -INFINITY;
-                }
+                att_mask_tail(sc[u], ragged, last - kt * 32 - 4 * h);
                 float mx = sc[u][0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[u][r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = att_xhalf_max(mx);
                 const float mnew = fmaxf(mrun[u], mx * c);
                 alpha[u] = __builtin_amdgcn_exp2f(mrun[u] - mnew);
                 rescale[u] = __ballot(mnew != mrun[u]) != 0ull;
@@ -976,7 +999,7 @@ __global__ __launch_bounds__(256, 2) void attn_mfma_lds_kernel(const AttnMfmaArg
     unsigned char* yb = reinterpret_cast<unsigned char*>(a.y) + ((long long)hd * a.M + srow) * 64;
 #pragma unroll
     for (int u = 0; u < TQ; ++u) {
-        const float ltot = lrun[u] + __shfl_xor(lrun[u], 32, 64);
+        const float ltot = att_xhalf_sum(lrun[u]);
         const float inv = 1.0f / ltot;
         const int q = (qt * TQ + u) * 32 + l31;
         if (q <= last) {

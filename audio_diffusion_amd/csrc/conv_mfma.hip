@@ -187,6 +187,14 @@ ConvTile conv_tile(const adk_op& op)
     // (256co x 256pos and 128co x 512pos one-wave-per-SIMD tiles were measured 7-20 % slower.)
     // (an 8-wave 128co x 512pos tile, which halves the weight bytes staged per FLOP, measured within +-1 % of this one
     // on every level and on the whole call: the kernel is not bound by the L2 -> LDS fill)
+#if defined(ADK_EXP_BM512) || defined(ADK_EXP_BM1024)      // experiment builds only: position tile of the L = 512 / 1024 levels
+#ifdef ADK_EXP_BM512
+    if (op.L > 256 && op.L <= 512) return {128, ADK_EXP_BM512, false};
+#endif
+#ifdef ADK_EXP_BM1024
+    if (op.L > 512 && op.L <= 1024) return {128, ADK_EXP_BM1024, false};
+#endif
+#endif
     return {128, op.L >= 2048 ? 256 : 128, false};
 }
 

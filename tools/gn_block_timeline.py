@@ -38,7 +38,8 @@ def run(cin, L, B=16, res=False):
             e1.record()
     torch.cuda.synchronize()
     assert int(state[1].item()) == 0
-    nblk = B * ((L + 255) // 256) * (cin // 128)
+    bm = 256 if L >= 2048 else (128 if L > 256 else 64)      # conv_tile() of conv_mfma.hip
+    nblk = B * ((L + bm - 1) // bm) * (cin // 128)
     n = min(nblk, 16384)
     buf = np.zeros(16384 * 9, dtype=np.uint64)
     raw.adk_exp_ts_gn.argtypes = [C.c_void_p, C.c_size_t]
@@ -90,6 +91,10 @@ if "--solo" in sys.argv:      # K loop of a block that has its CU to itself (256
     run(256, 16384, B=4)
     run(512, 4096, B=4)
     run(512, 4096, B=8)
+elif "--mid" in sys.argv:     # one-generation launches of the middle levels (C = 512, 128 x 128 / 128 x 64 tiles)
+    run(512, 1024)
+    run(512, 512)
+    run(512, 256)
 else:
     run(128, 65536)
     run(128, 65536, res=True)

@@ -124,6 +124,12 @@ class _Plan:
         assert C % cb == 0, "concat halves must be whole channel chunks"
         return _TRef(t.off + which * (C // cb) * self._rows(t.L) * 64, C, t.L, t.f32, 0, owned=False)
 
+    def planes(self, t, c0, C):
+        """Channels c0 .. c0 + C of a buffer as a tensor of their own (whole channel chunks: a byte range)."""
+        cb = 16 if t.f32 else 32
+        assert c0 % cb == 0 and C % cb == 0, "plane ranges must be whole channel chunks"
+        return _TRef(t.off + (c0 // cb) * self._rows(t.L) * 64, C, t.L, t.f32, 0, owned=False)
+
     def free(self, *ts):
         for t in ts:
             if t is not None and t.owned:
@@ -321,17 +327,40 @@ class _Plan:
         self.free(z)
 
     # ---- module lowering -----------------------------------------------------------------
-    def res_block(self, blk, key, x, out=None, stats=False):
-        """ResConvBlock (reference blocks/blocks.py:66-76,14-15).  Does not free x."""
+    def last_block_joint(self, blk, x_f32=False):
+        """Can the last ResConvBlock (is_last: conv -> GN -> GELU -> conv, + 1x1 skip conv, no norm after the second conv;
+        reference blocks/blocks.py:66-76) end in ONE conv launch?  Its second conv and its skip conv are one convolution
+        over the channel concatenation [h1 | x] (the skip weights sit on the centre tap), so if the block input x and h1
+        are written into adjacent planes of one buffer the two launches and the f32 round trip of skip(x) become one."""
+        cb = 16 if (x_f32 or self.dtype == torch.float32) else 32
+        return (blk.is_last and isinstance(blk.skip, nn.Conv1d) and blk.skip.bias is None and blk.c_mid % cb == 0
+                and blk.skip.weight.shape[1] % cb == 0 and blk.main[3].weight.shape[2] % 2 == 1
+                and bool(getattr(self.model, "fold_last_skip", True)))
+
+    def res_block(self, blk, key, x, out=None, stats=False, joint=None):
+        """ResConvBlock (reference blocks/blocks.py:66-76,14-15).  Does not free x.  ``joint``: a buffer of c_mid + c_in
+        channels whose LAST c_in channels are x (last_block_joint)."""
         c1, g1, c2 = blk.main[0], blk.main[1], blk.main[3]
+        h1_out = self.planes(joint, 0, blk.c_mid) if joint is not None else None
         if self.gn_fusable(x, c1.weight, blk.c_mid):         # conv -> GroupNorm -> GELU as one launch
-            h1, _ = self.conv(x, key + "main.0", c1.weight, c1.bias, blk.c_mid,
+            h1, _ = self.conv(x, key + "main.0", c1.weight, c1.bias, blk.c_mid, out=h1_out,
                               gn=(key + "main.1", g1.weight, g1.bias, True))
         else:
             raw1, p1 = self.conv(x, key + "main.0", c1.weight, c1.bias, blk.c_mid, stats=True)
-            h1, _ = self.gn_apply(raw1, p1, key + "main.1", g1.weight, g1.bias, gelu=True)
+            h1, _ = self.gn_apply(raw1, p1, key + "main.1", g1.weight, g1.bias, gelu=True, out=h1_out)
             self.free(p1)
+            if h1_out is not None:
+                self.free(raw1)
         has_skip = isinstance(blk.skip, nn.Conv1d)
+        if joint is not None:
+            w2, ws = c2.weight.detach().float().cpu(), blk.skip.weight.detach().float().cpu()
+            k = w2.shape[2]
+            wcat = torch.zeros(blk.c_out, blk.c_mid + ws.shape[1], k)
+            wcat[:, :blk.c_mid] = w2
+            wcat[:, blk.c_mid:, k // 2] = ws[:, :, 0]
+            y, _ = self.conv(joint, key + "main.3+skip", wcat, c2.bias, blk.c_out, out_f32=True, out=out)
+            self.meta[-1]["flops"] = 2.0 * (blk.c_mid * k + ws.shape[1]) * blk.c_out * x.L * self.B    # not the zero taps
+            return y, None
         if blk.is_last:
             if has_skip:
                 r, _ = self.conv(x, key + "skip", blk.skip.weight, None, blk.c_out, out_f32=True)
@@ -525,10 +554,17 @@ class _Plan:
         self.level(net[3], "net.3.main.", cat)
         h, _ = self.res_block(net[4], "net.4.", cat)
         self.free(cat)
-        h2, _ = self.res_block(net[5], "net.5.", h)
-        self.free(h)
-        o, _ = self.res_block(net[6], "net.6.", h2)
-        self.free(h2)
+        if self.last_block_joint(net[6]) and net[6].skip.weight.shape[1] == net[5].c_out:
+            joint = self.tensor(net[6].c_mid + net[5].c_out, L0)
+            h2, _ = self.res_block(net[5], "net.5.", h, out=self.planes(joint, net[6].c_mid, net[5].c_out))
+            self.free(h)
+            o, _ = self.res_block(net[6], "net.6.", h2, joint=joint)
+            self.free(joint)
+        else:
+            h2, _ = self.res_block(net[5], "net.5.", h)
+            self.free(h)
+            o, _ = self.res_block(net[6], "net.6.", h2)
+            self.free(h2)
         if bands > 1:
             flat = self.raw(B * cx * L0 * 4)
             self._emit(_lib.OP_UNPACK_OUTPUT, {"x": ("arena", o.off), "y": ("arena", flat.off)}, L=L0, Cin=cx)

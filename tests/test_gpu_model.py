@@ -44,6 +44,30 @@ def test_tiny_forward_fp32(name):
     assert torch.equal(y, y2)
 
 
+@pytest.mark.parametrize("name", ["tiny_d3.npz", "tiny_d3_pqmf4.npz", "tiny_d3_k7_fir.npz"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_last_block_joint_conv_matches_two_launch_form(name, dtype):
+    """The last ResConvBlock's second conv and its 1x1 skip conv as ONE conv over the joint buffer [h1 | x]
+    (unet.py last_block_joint; reference blocks/blocks.py:66-76, is_last) against the two-launch form of the same plan:
+    same operands, only the fp32 summation order differs (skip terms join the accumulator instead of being added as an
+    f32 residual)."""
+    dev = torch.device("cuda:0")
+    z = load_npz(name)
+    x, t = torch.from_numpy(z["x"]).to(dev), torch.from_numpy(z["t"]).to(dev)
+    outs = []
+    for joint in (True, False):
+        m = build(z, dev)
+        m.compute_dtype = dtype
+        m.fold_last_skip = joint
+        outs.append(m(x, t))
+        plan = next(iter(m._plans.values()))
+        n_conv = sum(1 for i in range(plan.n_ops) if plan.ops[i].kind == 1)
+        outs.append(n_conv)
+    assert outs[1] == outs[3] - 1, "the joint form must save exactly one conv launch"
+    assert rel_err(outs[0], outs[2]) <= 2e-6
+    assert rel_err(outs[0], torch.from_numpy(z["y"])) <= (1e-4 if dtype == torch.float32 else 1e-2)
+
+
 @pytest.mark.parametrize("name", TINY)
 def test_tiny_forward_bf16(name):
     dev = torch.device("cuda:0")

@@ -82,12 +82,13 @@ def test_full_model_init_matches_reference_digest():
     # 168 k=5 + 36 out projections (the 36 qkv projections run inside the attention launches) + 5 skips: the other 14 skip convs (every one above the k-split levels but the
     # last block's) run inside the fused launch of their block's second conv (ADK_FLAG_SKIP_CONV)
     folded = sum(1 for i in range(plan.n_ops) if plan.ops[i].kind == _lib.OP_CONV and plan.ops[i].flags & _lib.FLAG_SKIP_CONV)
-    assert folded == 14 and kinds.count(_lib.OP_CONV) == 259 - folded - 36
-    m.fold_skip = False
+    # the last block's skip conv and its second conv are ONE conv over the joint buffer [h1 | x] (last_block_joint): - 1 more
+    assert folded == 14 and kinds.count(_lib.OP_CONV) == 259 - folded - 36 - 1
+    m.fold_skip = m.fold_last_skip = False
     nofold = _Plan(m, 1, 65536, torch.bfloat16, torch.device("cpu"))
     nofold.validate()
     assert [nofold.ops[i].kind for i in range(nofold.n_ops)].count(_lib.OP_CONV) == 259 - 36
-    m.fold_skip = True
+    m.fold_skip = m.fold_last_skip = True
     assert len({plan.ops[i].i1 for i in range(plan.n_ops) if plan.ops[i].flags & _lib.FLAG_FUSE_GN
                 and plan.ops[i].kind == _lib.OP_CONV}) == fused          # one ticket counter per fused conv
     m.fuse_gn = m.fold_attn_norm = False              # the unfused plan stays available (A/B, and > 512 tiles per sample)

@@ -172,15 +172,27 @@ __device__ __forceinline__ ConvTileId conv_tile_mainloop16(const ConvArgs& a, co
 
     // (the 32-bit per-lane offsets pass through an opaque asm at every use: the 64-bit source addresses are then formed
     // where they are used instead of living - and spilling - as seven loop-invariant register pairs)
+    const bool xnt = __builtin_amdgcn_readfirstlane(a.ncot) == 1;
     auto issue_unit = [&](int u, auto opaque) {  // u = kc * TAPS + tap, wave-uniform
         const int kc = u / TAPS, tap = u - kc * TAPS;
         if (tap == 0) {
             const unsigned char* xb = xg + kc * xplane;
             unsigned char* dst = xs + (kc % RX) * XBYTES + wave * 1024;
+#ifndef ADK_EXP_NO_NT_X
+            if (xnt) {                            // one co tile: nobody else reads this tile, keep it out of the L2's way
 #pragma unroll
-            for (int j = 0; j < XI; ++j) {
-                if constexpr (decltype(opaque)::value) asm volatile("" : "+v"(xsrc[j]));
-                glds16(xb + xsrc[j], dst + j * (NW * 1024));
+                for (int j = 0; j < XI; ++j) {
+                    if constexpr (decltype(opaque)::value) asm volatile("" : "+v"(xsrc[j]));
+                    glds16_nt(xb + xsrc[j], dst + j * (NW * 1024));
+                }
+            } else
+#endif
+            {
+#pragma unroll
+                for (int j = 0; j < XI; ++j) {
+                    if constexpr (decltype(opaque)::value) asm volatile("" : "+v"(xsrc[j]));
+                    glds16(xb + xsrc[j], dst + j * (NW * 1024));
+                }
             }
         }
         const unsigned char* wb = wg + kc * wchunk + (long long)tap * a.CoutPad * 64;

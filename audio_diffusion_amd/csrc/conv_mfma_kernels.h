@@ -228,6 +228,13 @@ __device__ __forceinline__ void glds16(const unsigned char* src, unsigned char* 
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// The same load marked non-temporal (sc0 nt): for the activation tiles of a conv with ONE co tile (C = 128), which no other
+// block reads again.  Round 3, same box: level-1 conv 241.6 -> 231.7 us; with two or four co tiles sharing a tile through
+// the XCD's L2 the hint costs 2-6 %, so the kernel takes it only when a.ncot == 1 (profiles/r03/v4_ab_nt_x_loads.txt).
+__device__ __forceinline__ void glds16_nt(const unsigned char* src, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 3);
+}
 
 template <bool EXT, typename T, typename TO, int TAPS, int WCO, int WPOS, int TCO, int TPOS, int DIL = 1>
 __global__ __launch_bounds__(256, 2) void conv_mfma_simple_kernel(const ConvArgs a)
@@ -265,6 +272,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_simple_kernel(const ConvArgs
     const long long xplane = a.M * 64;
     const long long wchunk = (long long)TAPS * a.CoutPad * 64;
 
+    const bool xnt = !EXT && __builtin_amdgcn_readfirstlane(a.ncot) == 1;    // one co tile: the X tile has no other reader
+                                            // (glds16_nt; not the dilated convs, whose neighbours share wide halos through the L2)
     auto stage = [&](int kc) {
         const unsigned char* xb = xg + kc * xplane;
         const unsigned char* wb = wg + kc * wchunk;
@@ -275,7 +284,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_simple_kernel(const ConvArgs
                 const int row = j * 16 + srow;
                 long long m = mrow0 + row;
                 m = m < 0 ? 0 : (m >= a.M ? a.M - 1 : m);
-                glds16(xb + m * 64 + ((sslot ^ ((row >> 2) & 3)) << 4), xs + j * 1024);
+                if (xnt) glds16_nt(xb + m * 64 + ((sslot ^ ((row >> 2) & 3)) << 4), xs + j * 1024);
+                else glds16(xb + m * 64 + ((sslot ^ ((row >> 2) & 3)) << 4), xs + j * 1024);
             }
         }
 #pragma unroll
@@ -436,13 +446,17 @@ __device__ __forceinline__ ConvTileId conv_tile_mainloop(const ConvArgs& a, cons
         wsrc[j] = (unsigned)((cobase + row) * 64 + ((sslot ^ ((row >> 2) & 3)) << 4));
     }
 
+    const bool xnt = !EXT && __builtin_amdgcn_readfirstlane(a.ncot) == 1;    // glds16_nt
     auto issue_unit = [&](int u) {               // u = kc * TAPS + tap, wave-uniform
         const int kc = u / TAPS, tap = u - kc * TAPS;
         if (tap == 0) {
             const unsigned char* xb = xg + kc * xplane;
             unsigned char* dst = xs + (kc % RX) * XBYTES + wave * 1024;
 #pragma unroll
-            for (int j = 0; j < XI; ++j) glds16(xb + xsrc[j], dst + j * (NW * 1024));
+            for (int j = 0; j < XI; ++j) {
+                if (xnt) glds16_nt(xb + xsrc[j], dst + j * (NW * 1024));
+                else glds16(xb + xsrc[j], dst + j * (NW * 1024));
+            }
         }
         const unsigned char* wb = wg + kc * wchunk + (long long)tap * a.CoutPad * 64;
         unsigned char* dst = ws + (u % RW) * WBYTES + wave * 1024;

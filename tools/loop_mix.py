@@ -1,3 +1,10 @@
+#!/usr/bin/env python3
+"""Static instruction mix of the loops of the shipped kernels whose name matches a regular expression:
+    python3 tools/loop_mix.py 'attn_mfma_lds_kernelIDF16_'
+For every backward branch it prints the body's counts by class (MFMA, v_exp, packed f32, other VALU, DS, VMEM, scalar) and
+the most frequent VALU opcodes.  STATIC counts: code behind a not-taken branch inside the loop (e.g. the tail mask of the
+attention kernels) is included, so read the listing (tools/isa_lint.py's disassembly) before concluding anything about
+the taken path.  Uses tools/isa_lint.py to unbundle and disassemble audio_diffusion_amd/libadk.so."""
 import sys, re, collections, tempfile
 sys.path.insert(0, '/root/repo/tools')
 import isa_lint as L

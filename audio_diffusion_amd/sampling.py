@@ -224,7 +224,7 @@ def _sample(model, x, steps, eta, warp, extra_args):
                 import warnings
                 warnings.warn(f"{e}; re-running with model.fuse_gn = False (GroupNorm as separate passes)")
                 model.fuse_gn = False
-                model._plans = {}
+                model.release_plans() if hasattr(model, "release_plans") else model._plans.clear()
 
     # generic path: any callable model (or eta > 0); the update still runs as one fused kernel
     lib = _lib.load()

@@ -841,7 +841,7 @@ class DiffusionAttnUnet1D(nn.Module):
             import warnings
             warnings.warn(f"{msg}; re-running with model.fuse_gn = False (GroupNorm as separate passes)")
             self.fuse_gn = False
-            self._plans = {}
+            self.release_plans()
         return out
 
     def fused_error(self, clear=True):

@@ -26,6 +26,17 @@ class _NoCompute(nn.Module):
                            "DiffusionAttnUnet1D (libadk plan), there is no eager path")
 
 
+def check_dropout_inactive(model):
+    """Dropout (blocks/blocks.py:96,100,111,132) is the identity in eval mode, which is the mode the reference samples in;
+    the plans therefore carry no dropout op.  A model left in train() mode with a non-zero rate would silently differ
+    from the reference (which WOULD drop): refuse that instead."""
+    if model.training:
+        for name, m in model.named_modules():
+            if isinstance(m, nn.Dropout) and m.p > 0 and m.training:
+                raise RuntimeError(f"{name}: dropout p={m.p} is active (model.train()); this build covers the sampling path - "
+                                   "call model.eval(), as the reference's sample() callers do")
+
+
 class ResConvBlock(_NoCompute):
     """keys: main.{0,3}.{weight,bias}, main.{1,4}.{weight,bias}, skip.weight (blocks/blocks.py:66-76)."""
 
@@ -57,12 +68,11 @@ class SelfAttention1d(_NoCompute):
         assert c_in % n_head == 0
         if c_in // n_head != 32:
             raise NotImplementedError("libadk attention supports head dim 32 (n_head = c // 32)")
-        if dropout_rate:
-            raise NotImplementedError("inference path: dropout must be 0")
         self.norm = nn.GroupNorm(1, c_in)
         self.n_head = n_head
         self.qkv_proj = nn.Conv1d(c_in, c_in * 3, 1)
         self.out_proj = nn.Conv1d(c_in, c_in, 1)
+        self.dropout = nn.Dropout(dropout_rate, inplace=True)       # identity in eval mode (check_dropout_inactive)
         self.c_in = c_in
 
 
@@ -222,6 +232,7 @@ class SelfAttentionMod1d(_NoCompute):
         self.n_head = n_head
         self.qkv_proj = nn.Conv1d(c_in, c_in * 3, 1)
         self.out_proj = nn.Conv1d(c_in, c_in, 1)
+        self.dropout = nn.Dropout(dropout_rate)                     # identity in eval mode (check_dropout_inactive)
         self.c_in = c_in
 
 

@@ -19,7 +19,7 @@ from torch import nn
 
 from . import _lib
 from .blocks import (AdaGN, DBlock, FourierFeatures, MappingNet, ResModConvBlock, SelfAttentionMod1d, UBlock, UNet)
-from .blocks import fold_down_weight
+from .blocks import fold_down_weight, check_dropout_inactive
 from .unet import _Plan, _ceil_to
 
 
@@ -416,6 +416,7 @@ class AudioDenoiserModel(nn.Module):
         return st["output"].clone()
 
     def forward(self, input, sigma, mapping_cond=None, unet_cond=None, log_sigma=True):
+        check_dropout_inactive(self)
         return self.run(input, sigma, mapping_cond, unet_cond, log_sigma)
 
 

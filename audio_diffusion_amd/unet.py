@@ -17,7 +17,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .blocks import (ResConvBlock, SelfAttention1d, SkipBlock, FourierFeatures, Downsample1d, Upsample1d,
+from .blocks import (check_dropout_inactive, ResConvBlock, SelfAttention1d, SkipBlock, FourierFeatures, Downsample1d, Upsample1d,
                      Downsample1d_2, Upsample1d_2, fold_down_weight, fold_up_weight)
 from .pqmf import CachedPQMF
 
@@ -810,6 +810,7 @@ class DiffusionAttnUnet1D(nn.Module):
 
     @torch.no_grad()
     def forward(self, x, t, cond=None, cond_aug_scale=None):
+        check_dropout_inactive(self)
         if not x.is_cuda:
             raise RuntimeError("DiffusionAttnUnet1D (MI355X build) runs on ROCm devices only; there is no CPU path")
         self.check_input(x)

@@ -140,6 +140,25 @@ def test_ctor_errors_mirror_reference():
         m.check_input(torch.zeros(1, 2, 1026))
 
 
+def test_dropout_is_identity_in_eval_and_refused_in_train():
+    """blocks/blocks.py:96,100,111,132: the reference's blocks take dropout_rate; it is the identity in eval mode (the
+    mode sample() callers use), so the plans carry no op for it - but an ACTIVE dropout must not be silently ignored."""
+    from audio_diffusion_amd.blocks import SelfAttention1d, ResModConvBlock, check_dropout_inactive
+    att = SelfAttention1d(64, 2, dropout_rate=0.1)          # used to raise NotImplementedError
+    assert sorted(att.state_dict()) == ["norm.bias", "norm.weight", "out_proj.bias", "out_proj.weight",
+                                        "qkv_proj.bias", "qkv_proj.weight"]
+    blk = ResModConvBlock(16, 32, 32, 32, dropout_rate=0.2)
+    for mod in (att, blk):
+        mod.train()
+        with pytest.raises(RuntimeError, match="dropout"):
+            check_dropout_inactive(mod)
+        mod.eval()
+        check_dropout_inactive(mod)
+    m = A.DiffusionAttnUnet1D(depth=3, c_mults=[32, 32, 64], n_attn_layers=1)
+    m.train()                                             # rate 0 everywhere: train() alone is fine
+    check_dropout_inactive(m)
+
+
 def test_arena_planner_reuses_and_never_overlaps():
     import random
     rnd = random.Random(0)
